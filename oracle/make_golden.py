@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by EXECUTING the reference notebook's own code.
+
+TEST INFRASTRUCTURE ONLY -- runs in the build container (needs /root/reference);
+never runs on the GPU box and is never imported by the product package.
+
+    python oracle/make_golden.py [/root/reference/main_svae.ipynb]
+
+What is executed from the notebook (nothing is copied into this repo):
+  * code cell 5  (nb:310-388)  utilities: LongTensor / is_cuda_available globals
+  * code cell 6  (nb:406-576)  DataReader  (iter / iter_eval build x and dense y_s)
+  * code cell 7  (nb:594-666)  evaluate()
+  * code cell 8  (nb:684-768)  Encoder / Decoder / Model
+  * code cell 9  (nb:790-812)  VAELoss
+  * the ``def train`` node of code cell 10 (nb:1182-1233), extracted with ``ast``
+    (the rest of that cell is the driver script that needs the CSV files).
+Shims needed to run 2018 code on CPU torch 2.10 (none changes arithmetic):
+  * ``torch.Tensor.cuda`` -> identity (iter_eval calls .cuda() unconditionally, nb:548)
+  * criterion wrapper returning shape [1] so ``.data[0]`` (nb:617) indexes
+  * ``train_reader.num_b`` / ``batch_log_interval`` set so the log branch
+    (``total_loss[0]``, nb:1223) is never reached.
+Latent noise: the reference draws np.random.normal from numpy's GLOBAL stream
+(nb:744), shared with the user shuffle (nb:493).  We seed that stream, replay the
+same call sequence once to record order + eps, re-seed, then run the reference.
+"""
+import ast
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Variable
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import svae_numpy as O  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def load_reference(nb_path, hyper_params):
+    nb = json.load(open(nb_path))
+    code = ["".join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code"]
+    ns = dict(torch=torch, nn=nn, F=F, Variable=Variable, np=np, tqdm=lambda it: it,
+              hyper_params=hyper_params, os=os, json=json, time=__import__("time"))
+    for idx in (5, 6, 7, 8, 9):
+        exec(compile(code[idx], "nb_cell_%d" % idx, "exec"), ns)
+    tree = ast.parse(code[10])
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "train"][0]
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "nb_cell_10_train", "exec"), ns)
+    assert ns["is_cuda_available"] is False
+    return ns
+
+
+def hp_default(total_items, next_k=4, loss_type="next_k"):
+    return {
+        "history_split_test": [0.8, 0.2], "weight_decay": float(5e-3), "batch_size": 1,
+        "item_embed_size": 256, "rnn_size": 200, "hidden_size": 150, "latent_size": 64,
+        "loss_type": loss_type, "next_k": next_k, "number_users_to_keep": 1000000000,
+        "batch_log_interval": 10 ** 9, "train_cp_users": 200, "total_items": total_items,
+        "log_file": os.devnull,
+    }
+
+
+def synth_users(rs, n_users, total_items, lo, hi):
+    users = []
+    for _ in range(n_users):
+        n = int(rs.randint(lo, hi + 1))
+        users.append(rs.permutation(total_items)[:n].astype(np.int64))
+    return users
+
+
+def csv_lines(users, uid0=0):
+    lines = []
+    for u, items in enumerate(users):
+        for it in items:
+            lines.append("%d,%d,1\n" % (uid0 + u, int(it)))
+    return lines
+
+
+def load_params(model, p):
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in p.items()}
+    model.load_state_dict(sd)
+
+
+def case_forward_backward(ns_factory, name, total_items, lens, next_k, seed, anneal, loss_type="next_k"):
+    hp = hp_default(total_items, next_k, loss_type)
+    ns = ns_factory(hp)
+    rs = np.random.RandomState(seed)
+    users = [rs.permutation(total_items)[:n].astype(np.int64) for n in lens]
+    reader = ns["DataReader"](hp, csv_lines(users), None, total_items, True)
+    model = ns["Model"](hp)
+    p = O.make_params(total_items, seed)
+    load_params(model, p)
+    crit = ns["VAELoss"](hp)
+    out = dict(total_items=total_items, next_k=next_k, seed=seed, anneal=anneal,
+               n_users=len(users), loss_type=loss_type)
+    # the reference's own reader builds x and the dense targets (shuffled order, nb:493)
+    np.random.seed(seed)
+    order = list(range(len(users)))
+    np.random.shuffle(order)
+    np.random.seed(seed)
+    got = list(reader.iter())
+    assert len(got) == len(users)
+    for j, (x, y_s) in enumerate(got):
+        u = order[j]
+        T = x.shape[1]
+        np.random.seed(seed + 100 + j)
+        eps = np.random.normal(0, 1, size=(T, 64)).astype(np.float32)
+        np.random.seed(seed + 100 + j)
+        model.zero_grad()
+        dec_out, mu, ls = model(x)
+        loss = crit(dec_out, mu, ls, y_s, anneal)
+        loss.backward()
+        out["u%d_items" % j] = users[u]
+        out["u%d_x" % j] = x[0].numpy()
+        # dense y_s as sparse (row, col) pairs
+        nz = torch.nonzero(y_s[0]).numpy().astype(np.int32)
+        out["u%d_y_nz" % j] = nz
+        out["u%d_eps" % j] = eps
+        out["u%d_dec_out" % j] = dec_out[0].detach().numpy()
+        out["u%d_mu" % j] = mu.detach().numpy()
+        out["u%d_log_sigma" % j] = ls.detach().numpy()
+        out["u%d_loss" % j] = np.float64(loss.item())
+        if j == 0:
+            for k, v in model.named_parameters():
+                out["u0_grad/" + k] = v.grad.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
+def case_train(ns_factory, name, total_items, n_users, next_k, seed):
+    """The reference's train() (nb:1182-1233) over one tiny epoch, unmodified."""
+    hp = hp_default(total_items, next_k)
+    ns = ns_factory(hp)
+    rs = np.random.RandomState(seed)
+    users = synth_users(rs, n_users, total_items, 5, 30)
+    reader = ns["DataReader"](hp, csv_lines(users), None, total_items, True)
+    model = ns["Model"](hp)
+    load_params(model, O.make_params(total_items, seed))
+    real_crit = ns["VAELoss"](hp)
+    losses, anneals = [], []
+
+    def crit(dec, mu, ls, y, anneal):
+        v = real_crit(dec, mu, ls, y, anneal)
+        losses.append(float(v.item()))
+        anneals.append(float(anneal))
+        return v
+
+    opt = torch.optim.Adam(model.parameters(), weight_decay=hp["weight_decay"])   # nb:1260-1263
+
+    class FakeTrainReader:
+        num_b = 10 ** 9
+    ns.update(model=model, optimizer=opt, criterion=crit, epoch=1, train_reader=FakeTrainReader())
+    # replay the global numpy stream: shuffle, then one normal() per user in that order
+    np.random.seed(seed)
+    order = list(range(n_users))
+    np.random.shuffle(order)
+    eps = [np.random.normal(0, 1, size=(len(users[u]) - 1, 64)).astype(np.float32) for u in order]
+    np.random.seed(seed)
+    ns["train"](reader)
+    out = dict(total_items=total_items, next_k=next_k, seed=seed, n_users=n_users,
+               order=np.array(order), losses=np.array(losses), anneals=np.array(anneals))
+    for u in range(n_users):
+        out["items%d" % u] = users[u]
+    for j, e in enumerate(eps):
+        out["eps%d" % j] = e
+    for k, v in model.state_dict().items():
+        out["final/" + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "losses", losses[:3], "...", losses[-1])
+
+
+def case_batch_adam(ns_factory, name, total_items, lens_per_step, next_k, seed):
+    """Batched contract: loss = mean over users of the reference single-user VAELoss;
+    torch autograd + torch.optim.Adam(weight_decay=5e-3) for len(lens_per_step) steps."""
+    hp = hp_default(total_items, next_k)
+    ns = ns_factory(hp)
+    rs = np.random.RandomState(seed)
+    model = ns["Model"](hp)
+    load_params(model, O.make_params(total_items, seed))
+    crit = ns["VAELoss"](hp)
+    opt = torch.optim.Adam(model.parameters(), weight_decay=hp["weight_decay"])
+    out = dict(total_items=total_items, next_k=next_k, seed=seed, n_steps=len(lens_per_step))
+    losses = []
+    for s, lens in enumerate(lens_per_step):
+        users = [rs.permutation(total_items)[:n].astype(np.int64) for n in lens]
+        anneal = O.anneal_for_batch(s + 1, total_anneal_steps=20)   # fast schedule so KL grads matter
+        opt.zero_grad()
+        tot = 0.0
+        for j, items in enumerate(users):
+            x, tgt = O.build_inputs_targets(items, next_k)
+            y = torch.from_numpy(O.dense_targets(tgt, total_items))[None]
+            sd = seed + 1000 * s + j
+            np.random.seed(sd)
+            eps = np.random.normal(0, 1, size=(len(x), 64)).astype(np.float32)
+            np.random.seed(sd)
+            dec, mu, ls = model(torch.from_numpy(x)[None])
+            tot = tot + crit(dec, mu, ls, y, anneal) / float(len(users))
+            out["s%d_u%d_items" % (s, j)] = items
+            out["s%d_u%d_eps" % (s, j)] = eps
+        tot.backward()
+        if s == 0:
+            for k, v in model.named_parameters():
+                out["s0_grad/" + k] = v.grad.detach().numpy().copy()
+        opt.step()
+        losses.append(float(tot.item()))
+        out["s%d_n_users" % s] = len(users)
+        out["s%d_anneal" % s] = anneal
+    out["losses"] = np.array(losses)
+    for k, v in model.state_dict().items():
+        out["final/" + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "losses", losses)
+
+
+def case_eval(ns_factory, name, total_items, n_users, next_k, seed, is_train_set):
+    """The reference's evaluate() (nb:594-666) + iter_eval (nb:528-576), unmodified."""
+    hp = hp_default(total_items, next_k)
+    hp["train_cp_users"] = 4
+    ns = ns_factory(hp)
+    rs = np.random.RandomState(seed)
+    model = ns["Model"](hp)
+    p = O.make_params(total_items, seed)
+    # make scores less flat so rankings are well separated
+    p["decoder.linear2.weight"] *= 6.0
+    load_params(model, p)
+    real_crit = ns["VAELoss"](hp)
+    crit = lambda *a: real_crit(*a).view(1)      # .data[0] (nb:617) needs a 1-d tensor
+    full = synth_users(rs, n_users, total_items, 12, 60)
+    if is_train_set:
+        reader = ns["DataReader"](hp, csv_lines(full), None, total_items, True)
+        fold = [u[:int(0.8 * len(u))] for u in full]
+        held = [u[int(0.8 * len(u)):] for u in full]
+    else:
+        fold = [u[:int(0.8 * len(u))] for u in full]
+        held = [u[int(0.8 * len(u)):] for u in full]
+        reader = ns["DataReader"](hp, csv_lines(fold), csv_lines(held), total_items, False)
+    n_eval = min(n_users, hp["train_cp_users"]) if is_train_set else n_users
+    np.random.seed(seed)
+    eps = [np.random.normal(0, 1, size=(len(fold[u]) - 1, 64)).astype(np.float32) for u in range(n_eval)]
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        np.random.seed(seed)
+        metrics, len_map = ns["evaluate"](model, crit, reader, hp, is_train_set)
+        # per-user last-row logits and reference ranking (same noise)
+        last, top = [], []
+        for u in range(n_eval):
+            x = torch.from_numpy(fold[u][:-1])[None]
+            # re-seed and skip the draws of the users before u: same noise as inside evaluate()
+            np.random.seed(seed)
+            for v in range(u):
+                np.random.normal(0, 1, size=(len(fold[v]) - 1, 64))
+            dec, _, _ = model(x)
+            dec = dec.data
+            xs = torch.zeros(dec.shape[0], dec.shape[2])
+            xs[0, :].scatter_(0, x[0], 1.0)
+            lp = dec[:, -1, :] - (torch.abs(dec[:, -1, :] * xs) * 100000000)
+            _, argsorted = torch.sort(-1.0 * lp[0])
+            last.append(dec[0, -1].numpy().copy())
+            top.append(argsorted[:100].numpy().copy())
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    out = dict(total_items=total_items, next_k=next_k, seed=seed, n_users=n_users, n_eval=n_eval,
+               is_train_set=is_train_set, w3_scale=6.0,
+               metric_names=np.array(list(metrics.keys())),
+               metric_values=np.array([metrics[k] for k in metrics], dtype=np.float64),
+               len_map_keys=np.array(sorted(len_map.keys())),
+               last_logits=np.stack(last), top100=np.stack(top))
+    for kk in sorted(len_map.keys()):
+        out["len_map/%d" % kk] = np.array(len_map[kk], dtype=np.float64)
+    for u in range(n_users):
+        out["fold%d" % u] = fold[u]
+        out["held%d" % u] = held[u]
+    for u in range(n_eval):
+        out["eps%d" % u] = eps[u]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, metrics)
+
+
+def main():
+    nb_path = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/main_svae.ipynb"
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    factory = lambda hp: load_reference(nb_path, hp)
+    case_forward_backward(factory, "fwd_bwd_I97_k4", 97, [18, 5, 9], 4, 11, 0.05)
+    case_forward_backward(factory, "fwd_bwd_I211_k1", 211, [51, 3], 1, 12, 0.2, loss_type="predict_next")
+    case_forward_backward(factory, "fwd_bwd_I64_postfix", 64, [7, 6], 4, 13, 0.1, loss_type="postfix")
+    case_train(factory, "train_I97", 97, 12, 4, 21)
+    case_batch_adam(factory, "batch_adam_I97", 97, [[9, 17, 5], [30, 6, 6, 12], [4, 8]], 4, 31)
+    case_eval(factory, "eval_val_I211", 211, 6, 4, 41, False)
+    case_eval(factory, "eval_train_I211", 211, 7, 4, 42, True)
+
+
+if __name__ == "__main__":
+    main()
