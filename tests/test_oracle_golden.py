@@ -145,6 +145,6 @@ def test_evaluate_matches_reference_evaluate(golden_dir, name):
     for u in range(n_eval):
         x = fold[u][:-1]
         fwd = O.forward(p, x, eps[u], np.float32)
-        np.testing.assert_allclose(fwd["dec_out"][-1], g["last_logits"][u], rtol=2e-4, atol=2e-6)
+        _close(fwd["dec_out"][-1], g["last_logits"][u], 2e-4, 2e-6)
         s = O.masked_scores(g["last_logits"][u], x)
         np.testing.assert_array_equal(O.topk_desc(s, 100), g["top100"][u])
