@@ -1,0 +1,79 @@
+"""ctypes binding of the C-ABI library ``csrc/libsvae_hip.so`` (declared in include/svae_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing, or a call
+returns non-zero, this module raises.  Nothing under ``oracle/`` is imported here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsvae_hip.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_F = _c.c_float
+_LL = _c.c_longlong
+_ULL = _c.c_ulonglong
+_U = _c.c_uint
+
+# name -> argtypes (all return int: 0 ok, <0 argument error, >0 hipError_t)
+SIGNATURES = {
+    "svae_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _P],
+    "svae_reduce_slabs": [_P, _P, _LL, _I, _LL, _P],
+    "svae_gru_fwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
+    "svae_gru_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
+    "svae_embed_fwd": [_P, _P, _P, _I, _I, _P],
+    "svae_embed_bwd": [_P, _P, _P, _P, _P, _I, _F, _P],
+    "svae_latent_fwd": [_P, _P, _P, _P, _I, _P],
+    "svae_latent_bwd": [_P, _P, _P, _P, _F, _P, _I, _P],
+    "svae_softmax_nll": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "svae_adam_step": [_P, _P, _P, _P, _LL, _I, _F, _F, _F, _F, _F, _F, _P],
+    "svae_colsum": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "svae_transpose": [_P, _P, _I, _I, _P],
+    "svae_loss_reduce": [_P, _P, _P, _P, _F, _I, _P, _P],
+    "svae_gather_rows": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "svae_masked_topk": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "svae_philox_normal": [_P, _P, _I, _ULL, _U, _P],
+    "svae_check_device": [],
+    "svae_abi_version": [],
+}
+
+_lib = None
+
+
+class SvaeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvaeHipError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C svae_cf_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _I
+    lib.svae_last_error.argtypes = []
+    lib.svae_last_error.restype = _c.c_char_p
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.svae_last_error().decode("utf-8", "replace")
+        raise SvaeHipError("%s failed (rc=%d): %s" % (name, rc, msg))
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

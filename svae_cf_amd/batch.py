@@ -1,0 +1,132 @@
+"""Batch plans: how a set of user sequences is laid out for the GPU step.
+
+The reference feeds ONE user per step as ``x [1,T]`` plus a dense one-hot target
+``y_s [1,T,I]`` built by T ``scatter_`` calls (DataReader.iter nb:485-526, next_k branch
+nb:509-513).  Here a batch of B users is packed TIME-MAJOR:
+
+  * users sorted by length (descending); ``nact[t]`` users are still running at timestep t;
+  * row r = row_off[t] + u holds timestep t of (sorted) user u  -> the GRU kernel sees the
+    active users of a timestep as one contiguous block, every other kernel sees R = sum_u T_u
+    independent rows;
+  * targets are an int32 ``tgt [R, K]`` table (-1 = padding) instead of the dense one-hot;
+  * per-row weights carry the batched loss contract (mean over users of the reference's
+    single-user loss): ``w_nll[r] = 1/(B*num_ones_u)`` (nb:803, nb:808),
+    ``w_kl[r] = 1/(B*T_u)`` (the ``torch.mean`` over rows of nb:797).
+"""
+import numpy as np
+import torch
+
+
+class BatchPlan:
+    """Device-resident description of one batch (all int32 / fp32 tensors)."""
+
+    __slots__ = ("B", "R", "Tmax", "K", "order", "lengths", "x", "tgt", "w_nll", "w_kl", "row_off",
+                 "nact", "last_row", "perm", "seg_off", "seg_item", "nseg", "row_key", "seen",
+                 "seen_off", "row_of", "device")
+
+    def to(self, device):
+        for name in ("x", "tgt", "w_nll", "w_kl", "row_off", "nact", "last_row", "perm", "seg_off",
+                     "seg_item", "row_key", "seen", "seen_off"):
+            setattr(self, name, getattr(self, name).to(device, non_blocking=True))
+        self.device = device
+        return self
+
+
+def build_plan(users, next_k, user_keys=None, device=None, pin=False):
+    """users: list of 1-D int arrays (chronological item ids, len >= 2).
+
+    next_k: number of following items that are targets of a timestep (reference
+    ``hyper_params['next_k']``; ``predict_next`` is 1, ``postfix`` is any value >= max length).
+    user_keys: int64 id per user for the counter-based noise stream (defaults to position).
+    """
+    B = len(users)
+    if B == 0:
+        raise ValueError("empty batch")
+    lens = np.array([len(u) - 1 for u in users], dtype=np.int64)
+    if lens.min() < 1:
+        raise ValueError("every user needs at least 2 items (the reference crashes on T=0, nb:803)")
+    order = np.argsort(-lens, kind="stable")
+    T = lens[order]
+    Tmax = int(T[0])
+    K = int(min(next_k, Tmax))
+    nact = (T[None, :] > np.arange(Tmax)[:, None]).sum(axis=1).astype(np.int32)
+    row_off = np.zeros(Tmax + 1, dtype=np.int32)
+    np.cumsum(nact, out=row_off[1:])
+    R = int(row_off[-1])
+    if user_keys is None:
+        user_keys = np.arange(B, dtype=np.int64)
+    user_keys = np.asarray(user_keys, dtype=np.int64)
+
+    x = np.empty(R, dtype=np.int32)
+    tgt = np.full((R, K), -1, dtype=np.int32)
+    w_nll = np.empty(R, dtype=np.float32)
+    w_kl = np.empty(R, dtype=np.float32)
+    row_key = np.empty(R, dtype=np.int64)
+    last_row = np.empty(B, dtype=np.int32)
+    seen_off = np.zeros(B + 1, dtype=np.int32)
+    np.cumsum(T, out=seen_off[1:])
+    seen = np.empty(int(seen_off[-1]), dtype=np.int32)
+    row_of = []
+    for u in range(B):
+        items = np.asarray(users[order[u]], dtype=np.int64)
+        Tu = int(T[u])
+        rows = row_off[:Tu] + u
+        row_of.append(rows)
+        x[rows] = items[:-1]
+        seen[seen_off[u]:seen_off[u + 1]] = items[:-1]
+        for j in range(K):
+            n = Tu - j
+            if n > 0:
+                tgt[rows[:n], j] = items[1 + j:1 + j + n]
+        row_key[rows] = (user_keys[order[u]] << 20) + np.arange(Tu)
+        last_row[u] = rows[-1]
+        w_kl[rows] = 1.0 / (B * Tu)
+    # a duplicate target inside a row counts once (scatter_ of 1.0, nb:510-513)
+    for j in range(1, K):
+        dup = (tgt[:, j:j + 1] == tgt[:, :j]).any(axis=1) & (tgt[:, j] >= 0)
+        tgt[dup, j] = -1
+    n_r = (tgt >= 0).sum(axis=1)
+    for u in range(B):
+        num_ones = float(n_r[row_of[u][0]])          # first timestep's target count (nb:803)
+        w_nll[row_of[u]] = 1.0 / (B * num_ones)
+    # rows sorted by item for the deterministic embedding scatter-add
+    perm = np.argsort(x, kind="stable").astype(np.int32)
+    xs = x[perm]
+    starts = np.flatnonzero(np.concatenate(([True], xs[1:] != xs[:-1])))
+    seg_item = xs[starts].astype(np.int32)
+    seg_off = np.concatenate((starts, [R])).astype(np.int32)
+
+    p = BatchPlan()
+    p.B, p.R, p.Tmax, p.K = B, R, Tmax, K
+    p.order = order
+    p.lengths = T
+    p.nseg = int(len(seg_item))
+    p.row_of = row_of
+    p.device = None
+
+    def t(a):
+        tt = torch.from_numpy(a)
+        return tt.pin_memory() if pin else tt
+    p.x, p.tgt, p.w_nll, p.w_kl = t(x), t(tgt), t(w_nll), t(w_kl)
+    p.row_off, p.nact, p.last_row = t(row_off), t(nact), t(last_row)
+    p.perm, p.seg_off, p.seg_item = t(perm), t(seg_off), t(seg_item)
+    p.row_key, p.seen, p.seen_off = t(row_key), t(seen), t(seen_off)
+    if device is not None:
+        p.to(device)
+    return p
+
+
+def pack_rows(plan, per_user, width, dtype=np.float32):
+    """Scatter per-user [T_u, width] arrays (ORIGINAL user order) into the plan's row order."""
+    out = np.zeros((plan.R, width), dtype=dtype)
+    for u in range(plan.B):
+        out[plan.row_of[u]] = np.asarray(per_user[plan.order[u]], dtype=dtype)
+    return out
+
+
+def unpack_rows(plan, rows_array):
+    """Inverse of pack_rows: list (original user order) of [T_u, width] arrays."""
+    out = [None] * plan.B
+    for u in range(plan.B):
+        out[plan.order[u]] = rows_array[plan.row_of[u]]
+    return out

@@ -1,0 +1,280 @@
+// Generic LDS-tiled MFMA GEMM for gfx950:  C[M,N] = epi( sum_k A(m,k) * B(k,n) )
+//
+// Two arithmetic modes, same tiling:
+//   PREC 0: exact fp32   v_mfma_f32_32x32x2_f32   (bit-for-bit an fmaf chain; parity gates)
+//   PREC 1: bf16 inputs  v_mfma_f32_32x32x16_bf16 (fp32 accumulate; operands rounded RNE while staging)
+// Operand layouts (all row-major fp32 in HBM):
+//   AL 0: A stored [M][K] (k contiguous)     AL 1: A stored [K][M] (m contiguous)
+//   BL 0: B stored [N][K] (k contiguous)     BL 1: B stored [K][N] (n contiguous)
+// so y = x W^T is (0,0), dx = dy W is (0,1), dW = dy^T x is (1,1) with A = dy, B = x.
+// Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.
+// Split-K over blockIdx.z writes one fp32 slab per split (deterministic; reduced by reduce_slabs).
+//
+// MFMA k-order freedom: the products only have to pair A(m,k) with B(k,n) for the same k, so a
+// lane may take 4 (fp32) / 8 (bf16) CONSECUTIVE k's from one 16-byte LDS read and feed them to
+// consecutive MFMA steps, as long as both operands use the same map.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDK32 = BK + 4;    // fp32, k-contiguous tile row stride (floats): 36 -> conflict-free b128
+constexpr int LDM32 = BM + 4;    // fp32, m-contiguous tile row stride (floats)
+constexpr int LDK16 = BK + 8;    // bf16, k-contiguous tile row stride (elements): 40 -> 80 B rows
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias; const float* aux;
+    int M, N, K, lda, ldb, ldc, ldaux;
+    int act;            // 0 none, 1 tanh, 2 multiply by (1 - aux^2)  (tanh backward)
+    int ktiles_per_split;
+    long long slab_stride;
+};
+
+template <int PREC, int L>
+struct Tile;  // LDS image of one operand tile (rows = m or n index, BK k's)
+
+// ---- fp32 tiles ----
+template <>
+struct Tile<0, 0> {  // k-contiguous source: image [128][36] floats
+    static constexpr int BYTES = 128 * LDK32 * 4;
+    static __device__ __forceinline__ void stage(float* s, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = tid + i * 256;
+            int row = idx >> 3, c4 = idx & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int gr = r0 + row, gk = k0 + 4 * c4;
+            if (gr < R && gk < K) v = *reinterpret_cast<const float4*>(g + (size_t)gr * ld + gk);
+            *reinterpret_cast<float4*>(s + row * LDK32 + 4 * c4) = v;
+        }
+    }
+    // fragment for MFMA steps kb..: lane (i = l&31, kk = l>>5) -> 4 consecutive k's
+    static __device__ __forceinline__ float4 frag(const float* s, int row, int kb, int kk) {
+        return *reinterpret_cast<const float4*>(s + row * LDK32 + kb + 4 * kk);
+    }
+};
+template <>
+struct Tile<0, 1> {  // m-contiguous source: image [32][132] floats
+    static constexpr int BYTES = BK * LDM32 * 4;
+    static __device__ __forceinline__ void stage(float* s, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = tid + i * 256;
+            int k = idx >> 5, c4 = idx & 31;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int gk = k0 + k, gr = r0 + 4 * c4;
+            if (gk < K && gr < R) v = *reinterpret_cast<const float4*>(g + (size_t)gk * ld + gr);
+            *reinterpret_cast<float4*>(s + k * LDM32 + 4 * c4) = v;
+        }
+    }
+    static __device__ __forceinline__ float4 frag(const float* s, int row, int kb, int kk) {
+        const float* p = s + (kb + 4 * kk) * LDM32 + row;
+        return make_float4(p[0], p[LDM32], p[2 * LDM32], p[3 * LDM32]);
+    }
+};
+
+// ---- bf16 tiles: image always [128][40] bf16, k contiguous ----
+template <>
+struct Tile<1, 0> {
+    static constexpr int BYTES = 128 * LDK16 * 2;
+    static __device__ __forceinline__ void stage(unsigned short* s, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = tid + i * 256;
+            int row = idx >> 3, c4 = idx & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int gr = r0 + row, gk = k0 + 4 * c4;
+            if (gr < R && gk < K) v = *reinterpret_cast<const float4*>(g + (size_t)gr * ld + gk);
+            uint2 pk;
+            pk.x = (unsigned)sv_f2bf(v.x) | ((unsigned)sv_f2bf(v.y) << 16);
+            pk.y = (unsigned)sv_f2bf(v.z) | ((unsigned)sv_f2bf(v.w) << 16);
+            *reinterpret_cast<uint2*>(s + row * LDK16 + 4 * c4) = pk;
+        }
+    }
+};
+template <>
+struct Tile<1, 1> {  // m-contiguous source, transposed while staging (4x4 register transpose)
+    static constexpr int BYTES = 128 * LDK16 * 2;
+    static __device__ __forceinline__ void stage(unsigned short* s, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
+        // 32 k x 128 m tile = 8 k-groups(4) x 32 m-groups(4) = 256 blocks of 4x4: one per thread
+        int kg = tid >> 5, mg = tid & 31;
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int gk = k0 + 4 * kg + j, gr = r0 + 4 * mg;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gk < K && gr < R) v[j] = *reinterpret_cast<const float4*>(g + (size_t)gk * ld + gr);
+        }
+        const float* f = reinterpret_cast<const float*>(v);
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            uint2 pk;
+            pk.x = (unsigned)sv_f2bf(f[0 * 4 + mm]) | ((unsigned)sv_f2bf(f[1 * 4 + mm]) << 16);
+            pk.y = (unsigned)sv_f2bf(f[2 * 4 + mm]) | ((unsigned)sv_f2bf(f[3 * 4 + mm]) << 16);
+            *reinterpret_cast<uint2*>(s + (4 * mg + mm) * LDK16 + 4 * kg) = pk;
+        }
+    }
+};
+
+template <int PREC, int AL, int BL>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using TA = Tile<PREC, AL>;
+    using TB = Tile<PREC, BL>;
+    using elem_t = typename std::conditional<PREC == 0, float, unsigned short>::type;
+    elem_t* sA = reinterpret_cast<elem_t*>(smem);
+    elem_t* sB = reinterpret_cast<elem_t*>(smem + TA::BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kt_begin = blockIdx.z * a.ktiles_per_split;
+    int kt_end = kt_begin + a.ktiles_per_split;
+    const int kt_total = (a.K + BK - 1) / BK;
+    if (kt_end > kt_total) kt_end = kt_total;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int li = lane & 31, kk = lane >> 5;
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int k0 = kt * BK;
+        TA::stage(sA, a.A, a.lda, m0, k0, a.M, a.K, tid);
+        TB::stage(sB, a.B, a.ldb, n0, k0, a.N, a.K, tid);
+        __syncthreads();
+        if constexpr (PREC == 0) {
+#pragma unroll
+            for (int kb = 0; kb < BK; kb += 8) {
+                float4 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = TA::frag(sA, wm + 32 * i + li, kb, kk);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = TB::frag(sB, wn + 32 * j + li, kb, kk);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                reinterpret_cast<const float*>(&fa[i])[s],
+                                reinterpret_cast<const float*>(&fb[j])[s], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < BK; kb += 16) {
+                bf16x8 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8*>(sA + (wm + 32 * i + li) * LDK16 + kb + 8 * kk);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fb[j] = *reinterpret_cast<const bf16x8*>(sB + (wn + 32 * j + li) * LDK16 + kb + 8 * kk);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* C = a.C + (size_t)blockIdx.z * a.slab_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + li;
+        if (n >= a.N) continue;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (m < a.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (a.act == 1) v = tanhf(v);
+                    if (a.act == 2) { const float y = a.aux[(size_t)m * a.ldaux + n]; v *= (1.0f - y * y); }
+                    C[(size_t)m * a.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int PREC, int AL, int BL>
+int launch(const GemmArgs& a, int nsplit, hipStream_t st) {
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nsplit);
+    size_t lds = Tile<PREC, AL>::BYTES + Tile<PREC, BL>::BYTES;
+    hipLaunchKernelGGL((gemm_kernel<PREC, AL, BL>), grid, dim3(256), lds, st, a);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n4,
+                                    int nsplit, long long slab_stride) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n4; i += step) {
+        float4 s = reinterpret_cast<const float4*>(slabs)[i];
+        for (int z = 1; z < nsplit; ++z) {
+            float4 v = reinterpret_cast<const float4*>(slabs + z * slab_stride)[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int svae_gemm(const float* A, const float* B, float* C, const float* bias, const float* aux, int M,
+                         int N, int K, int lda, int ldb, int ldc, int ldaux, int a_layout, int b_layout, int act,
+                         int prec, int nsplit, long long slab_stride, void* stream) {
+    SV_CHECK_ARG(A && B && C, "svae_gemm: null pointer");
+    SV_CHECK_ARG(M > 0 && N > 0 && K > 0, "svae_gemm: bad shape %d %d %d", M, N, K);
+    SV_CHECK_ARG((lda % 4) == 0 && (ldb % 4) == 0, "svae_gemm: lda/ldb must be multiples of 4");
+    SV_CHECK_ARG((a_layout == 1 && b_layout == 1) || (K % 4) == 0, "svae_gemm: k-contiguous operands need K %% 4 == 0");
+    SV_CHECK_ARG(a_layout == 0 || (M % 4) == 0, "svae_gemm: m-contiguous A needs M %% 4 == 0");
+    SV_CHECK_ARG(b_layout == 0 || (N % 4) == 0, "svae_gemm: n-contiguous B needs N %% 4 == 0");
+    SV_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "svae_gemm: operands must be 16-byte aligned");
+    SV_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || slab_stride >= (long long)M * ldc), "svae_gemm: bad split");
+    SV_CHECK_ARG(nsplit == 1 || (bias == nullptr && act == 0), "svae_gemm: split-K takes no epilogue");
+    SV_CHECK_ARG(act != 2 || aux, "svae_gemm: act 2 needs aux");
+    SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gemm: prec must be 0 (fp32) or 1 (bf16)");
+    GemmArgs a{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, ldaux, act, 0, slab_stride};
+    const int kt = (K + BK - 1) / BK;
+    a.ktiles_per_split = (kt + nsplit - 1) / nsplit;
+    hipStream_t st = (hipStream_t)stream;
+    const int key = prec * 4 + a_layout * 2 + b_layout;
+    switch (key) {
+        case 0: return launch<0, 0, 0>(a, nsplit, st);
+        case 1: return launch<0, 0, 1>(a, nsplit, st);
+        case 2: return launch<0, 1, 0>(a, nsplit, st);
+        case 3: return launch<0, 1, 1>(a, nsplit, st);
+        case 4: return launch<1, 0, 0>(a, nsplit, st);
+        case 5: return launch<1, 0, 1>(a, nsplit, st);
+        case 6: return launch<1, 1, 0>(a, nsplit, st);
+        case 7: return launch<1, 1, 1>(a, nsplit, st);
+    }
+    return svae_fail(-1, "svae_gemm: bad layout");
+}
+
+extern "C" int svae_reduce_slabs(const float* slabs, float* out, long long n, int nsplit, long long slab_stride,
+                                 void* stream) {
+    SV_CHECK_ARG(slabs && out && n > 0 && (n % 4) == 0 && nsplit >= 1 && (slab_stride % 4) == 0,
+                 "svae_reduce_slabs: bad arguments");
+    long long n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, out, n4, nsplit,
+                       slab_stride);
+    SV_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,486 @@
+// HBM-bound kernels of the SVAE step for gfx950: embedding gather / segmented scatter-add, latent
+// reparameterisation + KL, row log-softmax + next-k NLL over materialised logits, fused Adam(L2),
+// column sums (bias gradients), masked top-k, Philox normal noise, small helpers.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// item embedding (reference nn.Embedding call nb:756; backward = dense scatter-add via nb:1205)
+// ------------------------------------------------------------------------------------------------
+__global__ void embed_fwd_kernel(const float* __restrict__ table, const int* __restrict__ x, float* __restrict__ out,
+                                 int R, int I) {
+    // one wave per row: 64 lanes x float4 = 256 floats = one embedding row (1 KiB, fully coalesced)
+    const int lane = threadIdx.x & 63;
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int stride = gridDim.x * (blockDim.x >> 6);
+    for (; row < R; row += stride) {
+        int it = x[row];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it >= 0 && it < I) v = reinterpret_cast<const float4*>(table + (size_t)it * SV_E)[lane];
+        reinterpret_cast<float4*>(out + (size_t)row * SV_E)[lane] = v;
+    }
+}
+
+// Deterministic scatter-add: rows are pre-sorted by item on the host (perm), one wave sums the rows
+// of one item in a fixed order and stores the result -- no atomics, bitwise reproducible.
+__global__ void embed_bwd_kernel(const float* __restrict__ demb, const int* __restrict__ perm,
+                                 const int* __restrict__ seg_off, const int* __restrict__ seg_item,
+                                 float* __restrict__ gtable, int nseg, float scale) {
+    const int lane = threadIdx.x & 63;
+    int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int stride = gridDim.x * (blockDim.x >> 6);
+    for (; s < nseg; s += stride) {
+        const int b = seg_off[s], e = seg_off[s + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = b; i < e; ++i) {
+            const float4 v = reinterpret_cast<const float4*>(demb + (size_t)perm[i] * SV_E)[lane];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+        reinterpret_cast<float4*>(gtable + (size_t)seg_item[s] * SV_E)[lane] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// latent: mu / log_sigma split, z = mu + exp(log_sigma) * eps, KL row term
+// (reference Model.sample_latent nb:734-750, VAELoss KL nb:797).  log_sigma is exponentiated as a
+// log-std for sampling but enters KL as a log-variance: reproduced as is.
+// ------------------------------------------------------------------------------------------------
+__global__ void latent_fwd_kernel(const float* __restrict__ tmp, const float* __restrict__ eps, float* __restrict__ z,
+                                  float* __restrict__ kl_row, int R) {
+    // one wave per row, lane = latent dim
+    const int lane = threadIdx.x & 63;
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int stride = gridDim.x * (blockDim.x >> 6);
+    for (; row < R; row += stride) {
+        const float mu = tmp[(size_t)row * SV_L2 + lane];
+        const float ls = tmp[(size_t)row * SV_L2 + SV_L + lane];
+        const float sg = expf(ls);
+        z[(size_t)row * SV_L + lane] = mu + sg * eps[(size_t)row * SV_L + lane];
+        float kl = 0.5f * (-ls + sg + mu * mu - 1.0f);
+        kl = sv_wave_sum(kl);
+        if (lane == 0) kl_row[row] = kl;
+    }
+}
+
+// dtmp[:, :64] = dz + a*w[r]*mu ; dtmp[:, 64:] = dz*sigma*eps + a*w[r]*0.5*(exp(ls)-1),  a = anneal
+__global__ void latent_bwd_kernel(const float* __restrict__ tmp, const float* __restrict__ eps,
+                                  const float* __restrict__ dz, const float* __restrict__ w_kl, float anneal,
+                                  float* __restrict__ dtmp, int R) {
+    const int lane = threadIdx.x & 63;
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int stride = gridDim.x * (blockDim.x >> 6);
+    for (; row < R; row += stride) {
+        const float mu = tmp[(size_t)row * SV_L2 + lane];
+        const float ls = tmp[(size_t)row * SV_L2 + SV_L + lane];
+        const float sg = expf(ls);
+        const float g = dz[(size_t)row * SV_L + lane];
+        const float kw = anneal * w_kl[row];
+        dtmp[(size_t)row * SV_L2 + lane] = g + kw * mu;
+        dtmp[(size_t)row * SV_L2 + SV_L + lane] = g * sg * eps[(size_t)row * SV_L + lane] + kw * 0.5f * (sg - 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row log-softmax + next-k multinomial NLL over materialised logits, gradient written in place
+// (reference VAELoss.forward nb:802-808).  One workgroup per row; the row is read twice (second
+// read is an L2 hit for |items| up to ~1M) and written once.
+//   nll_row[r]  = sum_{valid targets} (lse - logit[tgt])
+//   dlogits[r,i] = w_nll[r] * (n_r * softmax[r,i] - y[r,i])      (n_r = valid targets in row r)
+// Pad columns I..ldI-1 are written as 0.
+// ------------------------------------------------------------------------------------------------
+template <bool WRITE_GRAD>
+__global__ __launch_bounds__(256) void softmax_nll_kernel(float* __restrict__ logits, const int* __restrict__ tgt,
+                                                           const float* __restrict__ w_nll, float* __restrict__ nll_row,
+                                                           float* __restrict__ lse_out, int I, int ldI, int K) {
+    __shared__ float red[8];
+    __shared__ float bc[2];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* lr = logits + (size_t)row * ldI;
+    const int n4 = I >> 2;
+    // pass 1: online max / sum-exp
+    float m = -INFINITY, s = 0.f;
+    for (int i = tid; i < n4; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(lr)[i];
+        const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        if (mx > m) { s *= expf(m - mx); m = mx; }
+        s += expf(v.x - m) + expf(v.y - m) + expf(v.z - m) + expf(v.w - m);
+    }
+    for (int i = (n4 << 2) + tid; i < I; i += 256) {
+        const float v = lr[i];
+        if (v > m) { s *= expf(m - v); m = v; }
+        s += expf(v - m);
+    }
+    const float wm = sv_wave_max(m);
+    s *= (m == -INFINITY) ? 0.f : expf(m - wm);
+    s = sv_wave_sum(s);
+    if (lane == 0) { red[wave] = wm; red[4 + wave] = s; }
+    __syncthreads();
+    if (tid == 0) {
+        float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float S = 0.f;
+        for (int w = 0; w < 4; ++w) S += red[4 + w] * expf(red[w] - M);
+        bc[0] = M + logf(S);
+        // targets: -1 = padding.  duplicates were removed on the host (the reference's scatter_ of 1.0
+        // makes a duplicate count once, nb:510-513)
+        float nll = 0.f;
+        int nr = 0;
+        for (int k = 0; k < K; ++k) {
+            const int it = tgt[(size_t)row * K + k];
+            if (it >= 0) { nll += bc[0] - lr[it]; ++nr; }
+        }
+        nll_row[row] = nll;
+        bc[1] = (float)nr;
+        if (lse_out) lse_out[row] = bc[0];
+    }
+    __syncthreads();
+    if (!WRITE_GRAD) return;
+    const float lse = bc[0];
+    const float w = w_nll[row];
+    const float c = bc[1] * w;
+    for (int i = tid; i < n4; i += 256) {
+        float4 v = reinterpret_cast<const float4*>(lr)[i];
+        v.x = c * expf(v.x - lse); v.y = c * expf(v.y - lse); v.z = c * expf(v.z - lse); v.w = c * expf(v.w - lse);
+        reinterpret_cast<float4*>(lr)[i] = v;
+    }
+    for (int i = (n4 << 2) + tid; i < ldI; i += 256) lr[i] = i < I ? c * expf(lr[i] - lse) : 0.f;
+    __syncthreads();
+    if (tid < K) {
+        const int it = tgt[(size_t)row * K + tid];
+        if (it >= 0) lr[it] -= w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam with L2 weight decay on one flat buffer (reference torch.optim.Adam defaults, nb:1260-1263)
+// ------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n4, float b1, float b2, float step_size,
+                            float inv_sqrt_bc2, float eps, float wd, float gscale) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        float4 Mv = reinterpret_cast<float4*>(m)[i];
+        float4 V = reinterpret_cast<float4*>(v)[i];
+        float* pp = reinterpret_cast<float*>(&P);
+        const float* gg = reinterpret_cast<const float*>(&G);
+        float* mm = reinterpret_cast<float*>(&Mv);
+        float* vv = reinterpret_cast<float*>(&V);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gr = gg[c] * gscale + wd * pp[c];
+            mm[c] = mm[c] + (gr - mm[c]) * (1.0f - b1);          // lerp, as torch does
+            vv[c] = vv[c] * b2 + gr * gr * (1.0f - b2);
+            const float denom = sqrtf(vv[c]) * inv_sqrt_bc2 + eps;
+            pp[c] = pp[c] - step_size * (mm[c] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = Mv;
+        reinterpret_cast<float4*>(v)[i] = V;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums of a [R][ld] matrix (bias gradients), deterministic two-stage
+// ------------------------------------------------------------------------------------------------
+__global__ void colsum_partial_kernel(const float* __restrict__ a, float* __restrict__ part, int R, int N, int ld,
+                                      int rows_per_block) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > R) r1 = R;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += a[(size_t)r * ld + n];
+    part[(size_t)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int nparts) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * N + n];
+    out[n] = s;
+}
+
+// out[c][r] = in[r][c]
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    int c = blockIdx.x * 32 + threadIdx.x, r = blockIdx.y * 32 + threadIdx.y;
+    for (int i = 0; i < 32; i += 8)
+        if (c < cols && r + i < rows) tile[threadIdx.y + i][threadIdx.x] = in[(size_t)(r + i) * cols + c];
+    __syncthreads();
+    int oc = blockIdx.y * 32 + threadIdx.x, orow = blockIdx.x * 32 + threadIdx.y;
+    for (int i = 0; i < 32; i += 8)
+        if (oc < rows && orow + i < cols) out[(size_t)(orow + i) * rows + oc] = tile[threadIdx.x][threadIdx.y + i];
+}
+
+// loss = sum_r ( w_nll[r]*nll_row[r] + anneal*w_kl[r]*kl_row[r] ); single workgroup, fixed order
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ nll_row,
+                                                            const float* __restrict__ kl_row,
+                                                            const float* __restrict__ w_nll,
+                                                            const float* __restrict__ w_kl, float anneal, int R,
+                                                            float* __restrict__ out) {
+    __shared__ double red[16][2];
+    double a = 0.0, b = 0.0;
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        a += (double)w_nll[r] * (double)nll_row[r];
+        b += (double)w_kl[r] * (double)kl_row[r];
+    }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double A = 0.0, Bv = 0.0;
+        for (int w = 0; w < 16; ++w) { A += red[w][0]; Bv += red[w][1]; }
+        out[0] = (float)(A + (double)anneal * Bv);  // total
+        out[1] = (float)A;                          // likelihood part
+        out[2] = (float)Bv;                         // KL part (un-annealed)
+    }
+}
+
+// gather rows: out[i][:] = in[idx[i]][:]  (n4 float4 per row)
+__global__ void gather_rows_kernel(const float* __restrict__ in, const int* __restrict__ idx, float* __restrict__ out,
+                                   int nrows, int ld_in4, int ld_out4, int n4) {
+    const int row = blockIdx.x;
+    if (row >= nrows) return;
+    const float4* src = reinterpret_cast<const float4*>(in) + (size_t)idx[row] * ld_in4;
+    float4* dst = reinterpret_cast<float4*>(out) + (size_t)row * ld_out4;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// masked top-k (reference evaluate(): mask nb:621-624, full sort nb:632, [:k] nb:636)
+// score_i = s_i - |s_i * m_i| * 1e8, m = one-hot of the user's INPUT items.  One workgroup per user;
+// K rounds of arg-max over a register-resident copy; ties -> lower item index first.
+// ------------------------------------------------------------------------------------------------
+constexpr int TOPK_EPT = 32;  // elements per thread (1024 threads -> up to 32768 items; larger I loops)
+__global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restrict__ scores, int ld,
+                                                            const int* __restrict__ seen, const int* __restrict__ seen_off,
+                                                            int I, int K, int* __restrict__ out_idx,
+                                                            float* __restrict__ out_val, float* __restrict__ work) {
+    __shared__ float rv[16];
+    __shared__ int ri[16];
+    __shared__ int win;
+    const int u = blockIdx.x, tid = threadIdx.x;
+    float* w = work + (size_t)u * ld;
+    const float* s = scores + (size_t)u * ld;
+    for (int i = tid; i < I; i += 1024) w[i] = s[i];
+    __syncthreads();
+    for (int i = seen_off[u] + tid; i < seen_off[u + 1]; i += 1024) {
+        const int it = seen[i];
+        if (it >= 0 && it < I) { const float v = s[it]; w[it] = v - fabsf(v * 1.0f) * 100000000.0f; }
+    }
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < I; i += 1024) {
+            const float v = w[i];
+            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { rv[tid >> 6] = bv; ri[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float fv = rv[0];
+            int fi = ri[0];
+            for (int q = 1; q < 16; ++q)
+                if (rv[q] > fv || (rv[q] == fv && ri[q] < fi)) { fv = rv[q]; fi = ri[q]; }
+            win = fi;
+            out_idx[(size_t)u * K + k] = fi;
+            out_val[(size_t)u * K + k] = fv;
+            if (fi >= 0 && fi < I) w[fi] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    (void)win;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller N(0,1), keyed by (seed) and counter (row_key[r], col/4, step):
+// replayable and independent of how users are sharded over GPUs.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__global__ void philox_normal_kernel(float* __restrict__ out, const long long* __restrict__ row_key, int R,
+                                     unsigned long long seed, unsigned step) {
+    // thread -> (row, group of 4 columns); 16 groups per row
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)R * 16;
+    if (i >= n) return;
+    const int row = (int)(i >> 4), grp = (int)(i & 15);
+    const unsigned long long key = (unsigned long long)row_key[row];
+    uint32_t c[4] = {(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)grp, step};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float4 o;
+    const float u0 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u1 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u3 = ((float)(c[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u1, &s0, &c0);
+    sincosf(6.283185307179586f * u3, &s1, &c1);
+    o.x = r0 * c0; o.y = r0 * s0; o.z = r1 * c1; o.w = r1 * s1;
+    reinterpret_cast<float4*>(out)[i] = o;
+}
+
+inline int wave_rows_grid(int rows) {
+    int b = (rows + 3) / 4;
+    return b < 1 ? 1 : (b > 4096 ? 4096 : b);
+}
+
+}  // namespace
+
+// Reference interface replaced: self.item_embed(x) (nb:756).
+extern "C" int svae_embed_fwd(const float* table, const int* x, float* out, int R, int I, void* stream) {
+    SV_CHECK_ARG(table && x && out && R > 0 && I > 0, "svae_embed_fwd: bad arguments");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(wave_rows_grid(R)), dim3(256), 0, (hipStream_t)stream, table, x, out, R, I);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Reference interface replaced: embedding backward inside loss.backward() (nb:1205).  gtable must be
+// zero-filled by the caller; only rows of items present in the batch are written.
+extern "C" int svae_embed_bwd(const float* demb, const int* perm, const int* seg_off, const int* seg_item,
+                              float* gtable, int nseg, float scale, void* stream) {
+    SV_CHECK_ARG(demb && perm && seg_off && seg_item && gtable && nseg > 0, "svae_embed_bwd: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(wave_rows_grid(nseg)), dim3(256), 0, (hipStream_t)stream, demb, perm,
+                       seg_off, seg_item, gtable, nseg, scale);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Reference interface replaced: Model.sample_latent (nb:734-750) + KL term of VAELoss (nb:797).
+extern "C" int svae_latent_fwd(const float* tmp, const float* eps, float* z, float* kl_row, int R, void* stream) {
+    SV_CHECK_ARG(tmp && eps && z && kl_row && R > 0, "svae_latent_fwd: bad arguments");
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(wave_rows_grid(R)), dim3(256), 0, (hipStream_t)stream, tmp, eps, z,
+                       kl_row, R);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int svae_latent_bwd(const float* tmp, const float* eps, const float* dz, const float* w_kl, float anneal,
+                               float* dtmp, int R, void* stream) {
+    SV_CHECK_ARG(tmp && eps && dz && w_kl && dtmp && R > 0, "svae_latent_bwd: bad arguments");
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(wave_rows_grid(R)), dim3(256), 0, (hipStream_t)stream, tmp, eps, dz,
+                       w_kl, anneal, dtmp, R);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Reference interface replaced: F.log_softmax + multinomial likelihood of VAELoss.forward (nb:802-808)
+// and its gradient.  write_grad != 0 overwrites logits with dlogits.
+extern "C" int svae_softmax_nll(float* logits, const int* tgt, const float* w_nll, float* nll_row, float* lse,
+                                int R, int I, int ldI, int K, int write_grad, void* stream) {
+    SV_CHECK_ARG(logits && tgt && nll_row && R > 0 && I > 0, "svae_softmax_nll: bad arguments");
+    SV_CHECK_ARG(ldI >= I && (ldI % 4) == 0 && K >= 1 && K <= 256, "svae_softmax_nll: bad ldI=%d / K=%d", ldI, K);
+    SV_CHECK_ARG(!write_grad || w_nll, "svae_softmax_nll: w_nll required for the gradient");
+    if (write_grad)
+        hipLaunchKernelGGL(softmax_nll_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, tgt, w_nll,
+                           nll_row, lse, I, ldI, K);
+    else
+        hipLaunchKernelGGL(softmax_nll_kernel<false>, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, tgt, w_nll,
+                           nll_row, lse, I, ldI, K);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Reference interface replaced: optimizer.step() with torch.optim.Adam(weight_decay=5e-3) (nb:1206, nb:1260-1263).
+// step is the 1-based step count; gscale multiplies the raw gradient first (1/world for data parallel sums).
+extern "C" int svae_adam_step(float* p, const float* g, float* m, float* v, long long n, int step, float lr, float b1,
+                              float b2, float eps, float wd, float gscale, void* stream) {
+    SV_CHECK_ARG(p && g && m && v && n > 0 && (n % 4) == 0 && step >= 1, "svae_adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    long long n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, b1, b2, step_size,
+                       inv_sqrt_bc2, eps, wd, gscale);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int svae_colsum(const float* a, float* out, float* partials, int R, int N, int ld, int nparts,
+                           void* stream) {
+    SV_CHECK_ARG(a && out && partials && R > 0 && N > 0 && ld >= N && nparts >= 1, "svae_colsum: bad arguments");
+    const int rpb = (R + nparts - 1) / nparts;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nparts), dim3(256), 0, (hipStream_t)stream, a,
+                       partials, R, N, ld, rpb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, out, N,
+                       nparts);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int svae_transpose(const float* in, float* out, int rows, int cols, void* stream) {
+    SV_CHECK_ARG(in && out && rows > 0 && cols > 0, "svae_transpose: bad arguments");
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream,
+                       in, out, rows, cols);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// out3 = {total loss, likelihood part, un-annealed KL part}
+extern "C" int svae_loss_reduce(const float* nll_row, const float* kl_row, const float* w_nll, const float* w_kl,
+                                float anneal, int R, float* out3, void* stream) {
+    SV_CHECK_ARG(nll_row && kl_row && w_nll && w_kl && out3 && R > 0, "svae_loss_reduce: bad arguments");
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nll_row, kl_row, w_nll, w_kl,
+                       anneal, R, out3);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int svae_gather_rows(const float* in, const int* idx, float* out, int nrows, int ld_in, int ld_out, int n,
+                                void* stream) {
+    SV_CHECK_ARG(in && idx && out && nrows > 0 && (ld_in % 4) == 0 && (ld_out % 4) == 0 && (n % 4) == 0,
+                 "svae_gather_rows: bad arguments");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows), dim3(256), 0, (hipStream_t)stream, in, idx, out, nrows,
+                       ld_in / 4, ld_out / 4, n / 4);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Reference interface replaced: seen-item mask + torch.sort(-scores)[:k] in evaluate() (nb:621-636).
+// work is a scratch copy of the scores, [n_users][ld].
+extern "C" int svae_masked_topk(const float* scores, int ld, const int* seen, const int* seen_off, int n_users, int I,
+                                int K, int* out_idx, float* out_val, float* work, void* stream) {
+    SV_CHECK_ARG(scores && seen && seen_off && out_idx && out_val && work, "svae_masked_topk: null pointer");
+    SV_CHECK_ARG(n_users > 0 && I > 0 && ld >= I && K >= 1 && K <= I, "svae_masked_topk: bad shape");
+    hipLaunchKernelGGL(masked_topk_kernel, dim3(n_users), dim3(1024), 0, (hipStream_t)stream, scores, ld, seen,
+                       seen_off, I, K, out_idx, out_val, work);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Reference interface replaced: np.random.normal(0, 1, size) in sample_latent (nb:744), as a counter-based stream.
+extern "C" int svae_philox_normal(float* out, const long long* row_key, int R, unsigned long long seed,
+                                  unsigned step, void* stream) {
+    SV_CHECK_ARG(out && row_key && R > 0, "svae_philox_normal: bad arguments");
+    const long long n = (long long)R * 16;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+                       row_key, R, seed, step);
+    SV_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,238 @@
+"""SVAE step engine: owns the flat parameter / gradient / Adam buffers and the activation
+workspace in HBM and drives the HIP kernels through the C-ABI (``_lib``).
+
+One engine per process (= per GPU).  Every launch goes to ``torch.cuda.current_stream()``;
+nothing here allocates inside a step once the workspace has reached its high-water mark,
+and nothing synchronises with the host (the loss stays on the device until asked for).
+
+Reference path replaced: Model.forward nb:752-768, VAELoss.forward nb:795-812,
+loss.backward() nb:1205, optimizer.step() nb:1206, scoring in evaluate() nb:615-636.
+"""
+import math
+
+import torch
+
+from . import _lib
+from .layout import D, DP, E, G, HP, L, ParamLayout
+
+PREC_FP32 = 0
+PREC_BF16 = 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class SVAEEngine:
+    def __init__(self, total_items, device="cuda", prec=PREC_FP32, lr=1e-3, betas=(0.9, 0.999),
+                 adam_eps=1e-8, weight_decay=5e-3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("SVAEEngine needs a GPU: the HIP path has no CPU fallback")
+        _lib.load()
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            _lib.call("svae_check_device")
+        self.layout = ParamLayout(total_items)
+        self.I, self.IP = self.layout.I, self.layout.IP
+        self.prec = prec
+        self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
+        n = self.layout.total
+        f32 = dict(device=self.device, dtype=torch.float32)
+        self.params = torch.zeros(n, **f32)
+        self.grads = torch.zeros(n, **f32)
+        self.exp_avg = torch.zeros(n, **f32)
+        self.exp_avg_sq = torch.zeros(n, **f32)
+        self.step_count = 0
+        self.whh_t = torch.zeros(HP * G, **f32)
+        self.loss_out = torch.zeros(4, **f32)
+        self.cap = 0
+        self.ws = {}
+        self.nsplit = 32
+        self.slabs = torch.zeros(self.nsplit * G * E, **f32)        # largest split-K output: dW_ih
+        self.colparts = torch.zeros(64 * max(self.IP, G), **f32)
+        self._plan = None
+        self._anneal = 0.0
+
+    # ------------------------------------------------------------------ parameters
+    def P(self, name):
+        return self.layout.view(self.params, name)
+
+    def Gv(self, name):
+        return self.layout.view(self.grads, name)
+
+    def load_state_dict(self, sd):
+        self.layout.pack(sd, self.params)
+
+    def state_dict(self):
+        return self.layout.unpack(self.params)
+
+    def grad_dict(self):
+        return self.layout.unpack(self.grads)
+
+    def reset_optimizer(self):
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ workspace
+    def _ensure(self, R):
+        if R <= self.cap:
+            return
+        cap = int(R * 1.25) + 64
+        f32 = dict(device=self.device, dtype=torch.float32)
+        shapes = dict(emb=E, gi=G, hs=HP, gates=5 * HP, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
+                      logits=self.IP, dz=L, dtmp=2 * L, dd1=DP, denc=DP, dhs=HP, dgi=G, dgh=G, demb=E,
+                      kl_row=1, nll_row=1, lse=1)
+        self.ws = {k: torch.empty(cap * w, **f32) for k, w in shapes.items()}
+        self.cap = cap
+
+    def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, al, bl, bias=None, act=0, aux=None, ldaux=0,
+              nsplit=1, slab_stride=0):
+        _lib.call("svae_gemm", A.data_ptr(), B.data_ptr(), C.data_ptr(), _lib.ptr(bias), _lib.ptr(aux),
+                  M, N, K, lda, ldb, ldc, ldaux, al, bl, act, self.prec, nsplit, slab_stride, _stream())
+
+    def _wgrad(self, dY, X, out, R, N, K, ldy, ldx):
+        """out[N][K] = dY[R][N]^T X[R][K] with split-K over rows (deterministic slab reduce)."""
+        ns = max(1, min(self.nsplit, (R + 255) // 256))
+        if ns == 1:
+            self._gemm(dY, X, out, N, K, R, ldy, ldx, K, 1, 1)
+        else:
+            stride = N * K
+            self._gemm(dY, X, self.slabs, N, K, R, ldy, ldx, K, 1, 1, nsplit=ns, slab_stride=stride)
+            _lib.call("svae_reduce_slabs", self.slabs.data_ptr(), out.data_ptr(), stride, ns, stride, _stream())
+
+    def _colsum(self, A, out, R, N, ld):
+        nparts = max(1, min(64, (R + 127) // 128))
+        _lib.call("svae_colsum", A.data_ptr(), out.data_ptr(), self.colparts.data_ptr(), R, N, ld, nparts, _stream())
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, plan, anneal=0.0, eps=None, seed=0, step=0, want_grad=True, want_loss=True):
+        """Encoder GRU -> latent -> decoder -> logits (+ loss and dlogits).
+
+        eps: optional [R, 64] fp32 device tensor in plan row order (parity mode: the reference's
+        np.random.normal draws, nb:744); otherwise Philox noise keyed by (seed, step, row_key).
+        After the call ``ws['logits']`` holds the logits (want_grad=False) or dlogits (want_grad=True).
+        """
+        R = plan.R
+        self._ensure(R)
+        w, st = self.ws, _stream()
+        self._plan, self._anneal = plan, float(anneal)
+        _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
+                  w["emb"].data_ptr(), R, self.I, st)
+        self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
+                   bias=self.P("gru.bias_ih_l0"))
+        _lib.call("svae_gru_fwd", w["gi"].data_ptr(), self.P("gru.weight_hh_l0").data_ptr(),
+                  self.P("gru.bias_hh_l0").data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(),
+                  plan.B, plan.Tmax, w["hs"].data_ptr(), w["gates"].data_ptr(), 0, st)
+        self._gemm(w["hs"], self.P("encoder.linear1.weight"), w["enc"], R, DP, HP, HP, HP, DP, 0, 0,
+                   bias=self.P("encoder.linear1.bias"), act=1)
+        self._gemm(w["enc"], self.P("linear1.weight"), w["tmp"], R, 2 * L, DP, DP, DP, 2 * L, 0, 0,
+                   bias=self.P("linear1.bias"))
+        if eps is not None:
+            if eps.numel() != R * L:
+                raise ValueError("eps must have %d x %d elements" % (R, L))
+            w["eps"][:R * L].copy_(eps.reshape(-1))
+        else:
+            _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
+                      int(step) & 0xFFFFFFFF, st)
+        _lib.call("svae_latent_fwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["z"].data_ptr(),
+                  w["kl_row"].data_ptr(), R, st)
+        self._gemm(w["z"], self.P("decoder.linear1.weight"), w["d1"], R, DP, L, L, L, DP, 0, 0,
+                   bias=self.P("decoder.linear1.bias"), act=1)
+        self._gemm(w["d1"], self.P("decoder.linear2.weight"), w["logits"], R, self.I, DP, DP, DP, self.IP, 0, 0,
+                   bias=self.P("decoder.linear2.bias"))
+        if want_loss:
+            _lib.call("svae_softmax_nll", w["logits"].data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
+                      w["nll_row"].data_ptr(), w["lse"].data_ptr(), R, self.I, self.IP, plan.K,
+                      1 if want_grad else 0, st)
+            _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
+                      plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
+        return self.loss_out
+
+    def logits_rows(self, R):
+        return self.ws["logits"][:R * self.IP].view(R, self.IP)[:, :self.I]
+
+    def mu_logsigma(self, R):
+        t = self.ws["tmp"][:R * 2 * L].view(R, 2 * L)
+        return t[:, :L], t[:, L:]
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dlogits_ready=True, dmu=None, dls=None):
+        """Gradients of the batched loss w.r.t. every parameter into ``self.grads``.
+
+        Expects ``forward(..., want_grad=True)`` before it (ws['logits'] holds dlogits)."""
+        plan, anneal = self._plan, self._anneal
+        R, I, IP = plan.R, self.I, self.IP
+        w, st = self.ws, _stream()
+        lay = self.layout
+        dl = w["logits"]
+        # decoder.linear2
+        self._gemm(dl, w["d1"], self.Gv("decoder.linear2.weight"), IP, DP, R, IP, DP, DP, 1, 1)
+        self._colsum(dl, self.Gv("decoder.linear2.bias"), R, I, IP)
+        self._gemm(dl, self.P("decoder.linear2.weight"), w["dd1"], R, DP, IP, IP, DP, DP, 0, 1,
+                   act=2, aux=w["d1"], ldaux=DP)
+        # decoder.linear1
+        self._wgrad(w["dd1"], w["z"], self.Gv("decoder.linear1.weight"), R, DP, L, DP, L)
+        self._colsum(w["dd1"], self.Gv("decoder.linear1.bias"), R, DP, DP)
+        self._gemm(w["dd1"], self.P("decoder.linear1.weight"), w["dz"], R, L, DP, DP, L, L, 0, 1)
+        # latent
+        _lib.call("svae_latent_bwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["dz"].data_ptr(),
+                  plan.w_kl.data_ptr(), float(anneal), w["dtmp"].data_ptr(), R, st)
+        self._wgrad(w["dtmp"], w["enc"], self.Gv("linear1.weight"), R, 2 * L, DP, 2 * L, DP)
+        self._colsum(w["dtmp"], self.Gv("linear1.bias"), R, 2 * L, 2 * L)
+        self._gemm(w["dtmp"], self.P("linear1.weight"), w["denc"], R, DP, 2 * L, 2 * L, DP, DP, 0, 1,
+                   act=2, aux=w["enc"], ldaux=DP)
+        # encoder.linear1
+        self._wgrad(w["denc"], w["hs"], self.Gv("encoder.linear1.weight"), R, DP, HP, DP, HP)
+        self._colsum(w["denc"], self.Gv("encoder.linear1.bias"), R, DP, DP)
+        self._gemm(w["denc"], self.P("encoder.linear1.weight"), w["dhs"], R, HP, DP, DP, HP, HP, 0, 1)
+        # GRU (BPTT)
+        _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
+        _lib.call("svae_gru_bwd", w["dhs"].data_ptr(), w["hs"].data_ptr(), w["gates"].data_ptr(),
+                  self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
+                  w["dgi"].data_ptr(), w["dgh"].data_ptr(), 0, st)
+        hprev = w["gates"][4 * HP:]          # plane 4 of [R][5][224], row stride 5*224
+        self._wgrad(w["dgh"], hprev, self.Gv("gru.weight_hh_l0"), R, G, HP, G, 5 * HP)
+        self._colsum(w["dgh"], self.Gv("gru.bias_hh_l0"), R, G, G)
+        self._wgrad(w["dgi"], w["emb"], self.Gv("gru.weight_ih_l0"), R, G, E, G, E)
+        self._colsum(w["dgi"], self.Gv("gru.bias_ih_l0"), R, G, G)
+        self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
+        # embedding: dense gradient, zero + deterministic segmented scatter-add
+        ge = self.Gv("item_embed.weight")
+        ge.zero_()
+        _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
+                  plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, 1.0, st)
+
+    # ------------------------------------------------------------------ optimizer
+    def adam_step(self, gscale=1.0):
+        self.step_count += 1
+        _lib.call("svae_adam_step", self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                  self.exp_avg_sq.data_ptr(), self.layout.total, self.step_count, self.lr, self.betas[0],
+                  self.betas[1], self.adam_eps, self.weight_decay, float(gscale), _stream())
+
+    def train_step(self, plan, anneal, eps=None, seed=0, step=None):
+        """forward + backward + Adam for one batch.  Returns the device tensor holding
+        [loss, likelihood, KL]; reading it synchronises, so do that only when logging."""
+        self.forward(plan, anneal, eps=eps, seed=seed, step=self.step_count if step is None else step)
+        self.backward()
+        self.adam_step()
+        return self.loss_out
+
+    # ------------------------------------------------------------------ scoring
+    def score(self, plan, topk=100, eps=None, seed=0, step=0):
+        """evaluate()'s per-user work (nb:615-636): loss at anneal 0.2 over all rows, then the LAST
+        timestep's logits with the user's input items masked, ranked top-k.
+        Returns (loss_out, idx [B, k] int32, val [B, k]) in the plan's SORTED user order."""
+        self.forward(plan, 0.2, eps=eps, seed=seed, step=step, want_grad=False)
+        B, st = plan.B, _stream()
+        k = int(min(topk, self.I))
+        f32 = dict(device=self.device, dtype=torch.float32)
+        last = torch.empty(B * self.IP, **f32)
+        work = torch.empty(B * self.IP, **f32)
+        idx = torch.empty(B * k, device=self.device, dtype=torch.int32)
+        val = torch.empty(B * k, **f32)
+        _lib.call("svae_gather_rows", self.ws["logits"].data_ptr(), plan.last_row.data_ptr(), last.data_ptr(),
+                  B, self.IP, self.IP, self.IP, st)
+        _lib.call("svae_masked_topk", last.data_ptr(), self.IP, plan.seen.data_ptr(), plan.seen_off.data_ptr(),
+                  B, self.I, k, idx.data_ptr(), val.data_ptr(), work.data_ptr(), st)
+        return self.loss_out, idx.view(B, k), val.view(B, k), last.view(B, self.IP)[:, :self.I]
