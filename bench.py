@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Benchmark of the SVAE training step on MI355X (contract: see the task's bench.py section).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--prec bf16|fp32] [--batch B]
+
+A "step" = forward + backward + (gradient all-reduce) + Adam over one length-bucketed batch of
+B users per GPU, synthetic ML-20M-shaped sequences (138k users / 20k items / <=200 items per user;
+generator svae_cf_amd/synth.py, seed 98765), inputs resident in HBM before the timed region.
+Metric (BASELINE.json): train sequences/sec, whole job.  Weak scaling: B per GPU is fixed.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK = {"hbm": 8000.0, "bf16": 2500.0, "fp32": 157.3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--items", type=int, default=20000)
+    ap.add_argument("--nplans", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    from svae_cf_amd.dist import GradSync
+
+    I, B = args.items, args.batch
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    n_users = args.nplans * B * world
+    users = synth.make_users(n_users, I, mu, sigma, lmax, seed=98765)
+    rng = np.random.default_rng(98765)
+    batches = synth.bucketed_batches([len(u) for u in users], B, rng)
+    mine = [batches[i] for i in range(rank, len(batches) // world * world, world)]
+    plans = [S.build_plan([users[i] for i in idx], 4, user_keys=idx, device=dev) for idx in mine]
+    rows = float(np.mean([p.R for p in plans]))
+
+    prec = S.PREC_BF16 if args.prec == "bf16" else S.PREC_FP32
+    eng = S.SVAEEngine(I, device=dev, prec=prec)
+    torch.manual_seed(0)
+    sd = {}
+    for name, shp in eng.layout.ref_shapes.items():
+        if name == "item_embed.weight":
+            sd[name] = torch.randn(shp)
+        elif name.startswith("gru."):
+            sd[name] = (torch.rand(shp) * 2 - 1) / (200 ** 0.5)
+        elif name.endswith("weight"):
+            sd[name] = torch.randn(shp) * (2.0 / (shp[0] + shp[1])) ** 0.5
+        else:
+            sd[name] = (torch.rand(shp) * 2 - 1) * 0.05
+    eng.load_state_dict(sd)
+    if world > 1:
+        eng.grad_sync = GradSync(eng.grads, eng.layout.buckets())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        eng.train_step(plans[step % len(plans)], 0.01, seed=1234)
+        step += 1
+    tags = ["proj_fwd", "proj_dw", "proj_dx", "softmax_nll", "gru_fwd", "gru_bwd"]
+    eng.prof = {t: [] for t in tags}
+    barrier()
+    t0 = time.perf_counter()
+    users_done = 0
+    rows_done = 0
+    for _ in range(args.steps):
+        p = plans[step % len(plans)]
+        eng.train_step(p, 0.01, seed=1234)
+        users_done += p.B
+        rows_done += p.R
+        step += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    loss = float(eng.loss_out[0])
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    u = torch.tensor([float(users_done)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    dt, total_users = float(t[0]), float(u[0])
+
+    # per-kernel average durations measured over the timed region (events on the launch stream)
+    kt = {}
+    for tag, evs in eng.prof.items():
+        if evs:
+            kt[tag] = float(np.mean([a.elapsed_time(b) for a, b in evs]))     # ms
+    eng.prof = None
+    rows_step = rows_done / args.steps
+    IP = eng.IP
+    flops_gemm = 2.0 * rows_step * IP * 160          # one projection-sized GEMM (padded K = 160)
+    dominant = max(kt, key=kt.get) if kt else None
+    roofline = None
+    if dominant is not None:
+        ms = kt[dominant]
+        if dominant.startswith("proj_"):
+            ach = flops_gemm / (ms * 1e-3) / 1e12
+            peak = PEAK[args.prec]
+            roofline = dict(bound="mfma", kernel=dominant, achieved=ach, peak=peak, unit="TFLOP/s",
+                            frac=ach / peak, traffic=None, avg_ms=ms)
+        elif dominant == "softmax_nll":
+            byts = rows_step * IP * 4 * 2 + rows_step * 4 * 4
+            ach = byts / (ms * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=dominant, achieved=ach, peak=PEAK["hbm"], unit="GB/s",
+                            frac=ach / PEAK["hbm"], traffic=None, avg_ms=ms)
+        else:
+            fl = 2.0 * rows_step * 224 * 672
+            ach = fl / (ms * 1e-3) / 1e12
+            peak = PEAK["fp32"]
+            roofline = dict(bound="mfma", kernel=dominant, achieved=ach, peak=peak, unit="TFLOP/s",
+                            frac=ach / peak, traffic=None, avg_ms=ms)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import svae_torch as TP           # checker / baseline leg only
+        cb = TP.time_cpu_baseline(users[:80], I, next_k=4, warmup=2, budget_s=15.0, max_users=70)
+        cpu = dict(value=cb["value"], unit="sequences/s", cores=cb["cores"], kind="port",
+                   sample="%d users of the same synthetic ML-20M-shaped set, notebook-style B=1 fwd+bwd+Adam "
+                          "(dense fp32, torch CPU), %.1f s" % (cb["users"], cb["seconds"]))
+
+    if rank == 0:
+        out = {
+            "metric": "train sequences/sec (ML-20M shape)", "value": total_users / dt, "unit": "sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+            "config": {"workload": "ML-20M-shaped synthetic (configs[2]): 20000 items, seq<=200, "
+                                   "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam" % B,
+                       "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "parallelism": "dp%d" % world,
+                       "final_loss": loss},
+            "kernel_ms": kt, "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""User-sharded data parallelism (NEW in this build: the reference is single-process).
+
+One process per GPU.  Users (independent sequences) are sharded: every rank builds the same seeded
+global batch order and takes every world-th batch.  Parameters and Adam state are replicated; each
+step does ONE exchange: a sum all-reduce of the flat gradient buffer, issued per bucket in
+backward-readiness order (decoder.linear2 first, item_embed last) so RCCL works over xGMI while the
+rest of backward still runs; Adam then applies gscale = 1/world (mean over the union of users).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    """Bucketed asynchronous all-reduce over a flat gradient buffer."""
+
+    def __init__(self, flat_grads, buckets, group=None):
+        self.flat = flat_grads
+        self.buckets = list(buckets)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.pending = []
+
+    def bucket_ready(self, i):
+        """Call when every gradient of bucket i has been enqueued on the current stream."""
+        if self.world == 1:
+            return
+        s, e = self.buckets[i]
+        self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    @property
+    def gscale(self):
+        return 1.0 / self.world
+
+
+def shard_batches(batches, rank, world):
+    """Rank r takes batches r, r+world, ...; the tail that does not fill all ranks is dropped so
+    every rank runs the same number of steps (collectives stay matched)."""
+    n = len(batches) // world * world
+    return [batches[i] for i in range(rank, n, world)]
+
+
+def allreduce_metrics(values, device, group=None):
+    """Sum a small list of python floats over ranks (eval: loss sum, 6 metric sums, user count)."""
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.tolist()

@@ -35,6 +35,7 @@ class SVAEEngine:
         self.layout = ParamLayout(total_items)
         self.I, self.IP = self.layout.I, self.layout.IP
         self.prec = prec
+        self.gru_prec = 0              # bf16 GRU kernels not built yet: recurrence stays fp32
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
         n = self.layout.total
         f32 = dict(device=self.device, dtype=torch.float32)
@@ -52,6 +53,8 @@ class SVAEEngine:
         self.colparts = torch.zeros(64 * max(self.IP, G), **f32)
         self._plan = None
         self._anneal = 0.0
+        self.grad_sync = None          # dist.GradSync for data parallel runs
+        self.prof = None               # dict tag -> list of (start, end) torch.cuda.Event pairs
 
     # ------------------------------------------------------------------ parameters
     def P(self, name):
@@ -87,9 +90,29 @@ class SVAEEngine:
         self.cap = cap
 
     def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, al, bl, bias=None, act=0, aux=None, ldaux=0,
-              nsplit=1, slab_stride=0):
+              nsplit=1, slab_stride=0, tag=None):
+        ev = self._tic(tag)
         _lib.call("svae_gemm", A.data_ptr(), B.data_ptr(), C.data_ptr(), _lib.ptr(bias), _lib.ptr(aux),
                   M, N, K, lda, ldb, ldc, ldaux, al, bl, act, self.prec, nsplit, slab_stride, _stream())
+        self._toc(tag, ev)
+
+    def _tic(self, tag):
+        if self.prof is None or tag not in self.prof:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _toc(self, tag, ev):
+        if ev is None:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.prof[tag].append((ev, end))
+
+    def _bucket(self, i):
+        if self.grad_sync is not None:
+            self.grad_sync.bucket_ready(i)
 
     def _wgrad(self, dY, X, out, R, N, K, ldy, ldx):
         """out[N][K] = dY[R][N]^T X[R][K] with split-K over rows (deterministic slab reduce)."""
@@ -121,9 +144,11 @@ class SVAEEngine:
                   w["emb"].data_ptr(), R, self.I, st)
         self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
                    bias=self.P("gru.bias_ih_l0"))
+        ev = self._tic("gru_fwd")
         _lib.call("svae_gru_fwd", w["gi"].data_ptr(), self.P("gru.weight_hh_l0").data_ptr(),
                   self.P("gru.bias_hh_l0").data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(),
-                  plan.B, plan.Tmax, w["hs"].data_ptr(), w["gates"].data_ptr(), 0, st)
+                  plan.B, plan.Tmax, w["hs"].data_ptr(), w["gates"].data_ptr(), self.gru_prec, st)
+        self._toc("gru_fwd", ev)
         self._gemm(w["hs"], self.P("encoder.linear1.weight"), w["enc"], R, DP, HP, HP, HP, DP, 0, 0,
                    bias=self.P("encoder.linear1.bias"), act=1)
         self._gemm(w["enc"], self.P("linear1.weight"), w["tmp"], R, 2 * L, DP, DP, DP, 2 * L, 0, 0,
@@ -140,11 +165,13 @@ class SVAEEngine:
         self._gemm(w["z"], self.P("decoder.linear1.weight"), w["d1"], R, DP, L, L, L, DP, 0, 0,
                    bias=self.P("decoder.linear1.bias"), act=1)
         self._gemm(w["d1"], self.P("decoder.linear2.weight"), w["logits"], R, self.I, DP, DP, DP, self.IP, 0, 0,
-                   bias=self.P("decoder.linear2.bias"))
+                   bias=self.P("decoder.linear2.bias"), tag="proj_fwd")
         if want_loss:
+            ev = self._tic("softmax_nll")
             _lib.call("svae_softmax_nll", w["logits"].data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
                       w["nll_row"].data_ptr(), w["lse"].data_ptr(), R, self.I, self.IP, plan.K,
                       1 if want_grad else 0, st)
+            self._toc("softmax_nll", ev)
             _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
         return self.loss_out
@@ -167,10 +194,11 @@ class SVAEEngine:
         lay = self.layout
         dl = w["logits"]
         # decoder.linear2
-        self._gemm(dl, w["d1"], self.Gv("decoder.linear2.weight"), IP, DP, R, IP, DP, DP, 1, 1)
+        self._gemm(dl, w["d1"], self.Gv("decoder.linear2.weight"), IP, DP, R, IP, DP, DP, 1, 1, tag="proj_dw")
         self._colsum(dl, self.Gv("decoder.linear2.bias"), R, I, IP)
+        self._bucket(0)
         self._gemm(dl, self.P("decoder.linear2.weight"), w["dd1"], R, DP, IP, IP, DP, DP, 0, 1,
-                   act=2, aux=w["d1"], ldaux=DP)
+                   act=2, aux=w["d1"], ldaux=DP, tag="proj_dx")
         # decoder.linear1
         self._wgrad(w["dd1"], w["z"], self.Gv("decoder.linear1.weight"), R, DP, L, DP, L)
         self._colsum(w["dd1"], self.Gv("decoder.linear1.bias"), R, DP, DP)
@@ -186,22 +214,27 @@ class SVAEEngine:
         self._wgrad(w["denc"], w["hs"], self.Gv("encoder.linear1.weight"), R, DP, HP, DP, HP)
         self._colsum(w["denc"], self.Gv("encoder.linear1.bias"), R, DP, DP)
         self._gemm(w["denc"], self.P("encoder.linear1.weight"), w["dhs"], R, HP, DP, DP, HP, HP, 0, 1)
+        self._bucket(1)
         # GRU (BPTT)
         _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
+        ev = self._tic("gru_bwd")
         _lib.call("svae_gru_bwd", w["dhs"].data_ptr(), w["hs"].data_ptr(), w["gates"].data_ptr(),
                   self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
-                  w["dgi"].data_ptr(), w["dgh"].data_ptr(), 0, st)
+                  w["dgi"].data_ptr(), w["dgh"].data_ptr(), self.gru_prec, st)
+        self._toc("gru_bwd", ev)
         hprev = w["gates"][4 * HP:]          # plane 4 of [R][5][224], row stride 5*224
         self._wgrad(w["dgh"], hprev, self.Gv("gru.weight_hh_l0"), R, G, HP, G, 5 * HP)
         self._colsum(w["dgh"], self.Gv("gru.bias_hh_l0"), R, G, G)
         self._wgrad(w["dgi"], w["emb"], self.Gv("gru.weight_ih_l0"), R, G, E, G, E)
         self._colsum(w["dgi"], self.Gv("gru.bias_ih_l0"), R, G, G)
+        self._bucket(2)
         self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
         # embedding: dense gradient, zero + deterministic segmented scatter-add
         ge = self.Gv("item_embed.weight")
         ge.zero_()
         _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
                   plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, 1.0, st)
+        self._bucket(3)
 
     # ------------------------------------------------------------------ optimizer
     def adam_step(self, gscale=1.0):
@@ -215,7 +248,11 @@ class SVAEEngine:
         [loss, likelihood, KL]; reading it synchronises, so do that only when logging."""
         self.forward(plan, anneal, eps=eps, seed=seed, step=self.step_count if step is None else step)
         self.backward()
-        self.adam_step()
+        if self.grad_sync is not None:
+            self.grad_sync.wait()
+            self.adam_step(self.grad_sync.gscale)
+        else:
+            self.adam_step()
         return self.loss_out
 
     # ------------------------------------------------------------------ scoring

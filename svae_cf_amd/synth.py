@@ -1,0 +1,55 @@
+"""Synthetic user sequences shaped like the reference's datasets (no real data offline).
+
+Lengths: clip(round(lognormal(mu, sigma)), 5, Lmax) items per user.  Items: drawn from a Zipf(1.0)
+popularity over the catalogue mixed with a per-user latent cluster (64 clusters, each boosting a random
+2% of the items), duplicates removed keeping first occurrence = chronological order.
+"""
+import numpy as np
+
+SHAPES = {
+    # name: (users, items, mu, sigma, Lmax)
+    "ml-1m": (6040, 3483, 4.0, 1.0, 1000),
+    "ml-20m": (138000, 20000, 4.2, 0.9, 200),
+    "netflix": (480000, 17770, 4.6, 1.1, 1000),
+    "large": (1000000, 1000000, 3.5, 0.8, 200),
+}
+
+
+def make_users(n_users, total_items, mu, sigma, lmax, seed=98765, n_clusters=64):
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.rint(rng.lognormal(mu, sigma, n_users)), 5, min(lmax, total_items // 2)).astype(np.int64)
+    pop = 1.0 / np.arange(1, total_items + 1, dtype=np.float64)
+    cdf = np.cumsum(pop / pop.sum())
+    item_of_rank = rng.permutation(total_items)
+    csize = max(8, total_items // 50)
+    clusters = [rng.choice(total_items, csize, replace=False) for _ in range(n_clusters)]
+    users = []
+    for n in lens:
+        c = clusters[int(rng.integers(n_clusters))]
+        out = np.empty(0, dtype=np.int64)
+        while len(out) < n:
+            m = int(2 * n + 16)
+            z = item_of_rank[np.minimum(np.searchsorted(cdf, rng.random(m)), total_items - 1)]
+            cl = c[rng.integers(csize, size=m)]
+            draw = np.where(rng.random(m) < 0.5, cl, z)
+            out = np.concatenate((out, draw))
+            _, first = np.unique(out, return_index=True)
+            out = out[np.sort(first)]
+        users.append(out[:n].astype(np.int32))
+    return users
+
+
+def bucketed_batches(lengths, batch_size, rng, window=16):
+    """Length-bucketed batches: shuffle users, sort inside windows of window*batch_size users,
+    cut into batches, shuffle the batches.  Returns a list of index arrays."""
+    n = len(lengths)
+    perm = rng.permutation(n)
+    out = []
+    w = window * batch_size
+    for s in range(0, n, w):
+        idx = perm[s:s + w]
+        idx = idx[np.argsort(-np.asarray(lengths)[idx], kind="stable")]
+        for b in range(0, len(idx), batch_size):
+            out.append(idx[b:b + batch_size])
+    order = rng.permutation(len(out))
+    return [out[i] for i in order]

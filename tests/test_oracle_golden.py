@@ -148,3 +148,21 @@ def test_evaluate_matches_reference_evaluate(golden_dir, name):
         _close(fwd["dec_out"][-1], g["last_logits"][u], 2e-4, 2e-6)
         s = O.masked_scores(g["last_logits"][u], x)
         np.testing.assert_array_equal(O.topk_desc(s, 100), g["top100"][u])
+
+
+def test_torch_port_matches_reference(golden_dir):
+    """oracle/svae_torch.py (the cpu_baseline port) replays the reference's train() run."""
+    import torch
+    from oracle import svae_torch as TP
+    g = _load(golden_dir, "train_I97")
+    I, seed = int(g["total_items"]), int(g["seed"])
+    model = TP.TorchSVAE(I)
+    model.load_reference_state(O.make_params(I, seed))
+    opt = torch.optim.Adam(model.parameters(), weight_decay=5e-3)
+    users = [g["items%d" % u] for u in g["order"]]
+    eps = [g["eps%d" % j] for j in range(len(users))]
+    losses = TP.train_users(model, opt, users, 4, I, eps_list=eps, anneal_fn=O.anneal_for_batch)
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    sd = model.reference_state()
+    for k in O.PARAM_NAMES:
+        _param_gate(sd[k], g["final/" + k], k)
