@@ -39,6 +39,14 @@ int svae_fail(int code, const char* fmt, ...);
 
 __device__ __forceinline__ float sv_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// fast forms for the bf16 kernels: v_exp_f32 / v_rcp_f32 (about 1 ulp each)
+__device__ __forceinline__ float sv_sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float sv_tanh_fast(float x) {
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
+}
+
 // round-to-nearest-even f32 -> bf16 (plain cast form keeps NaN a NaN on gfx950)
 __device__ __forceinline__ unsigned short sv_f2bf(float x) {
     __hip_bfloat16 b = __float2bfloat16(x);

@@ -4,22 +4,32 @@
 // Layout: a batch is TIME-MAJOR PACKED.  Users are sorted by length (descending); at timestep t the
 // first nact[t] users are active and their rows are row_off[t] .. row_off[t]+nact[t]-1.  One workgroup
 // owns 16 consecutive users for ALL timesteps (users are independent, so there is no inter-workgroup
-// exchange); the hidden state lives in registers (fp32, owner lane) and in LDS (matmul operand).
+// exchange).  4 waves, one per SIMD; wave w owns hidden-unit tiles jt = w, w+4, w+8, w+12 (< 14) and
+// all three gates of those units, so the gate math needs no cross-wave exchange: a lane owns hidden
+// unit j = 16*jt + (lane & 15) of users m = 4*(lane >> 4) + r, r = 0..3 (the MFMA C layout), keeps
+// h[m][j] in a register (fp32) and publishes it to LDS as the next step's matmul operand.
 //
 // The input-side gates gi = emb W_ih^T + b_ih for all rows are computed beforehand by one big GEMM.
 // This file: the recurrent part, gh = h_{t-1} W_hh^T + b_hh, the fused gate math, and the reverse-time
-// BPTT that produces dgi / dgh for the weight-gradient GEMMs.
+// BPTT that produces dgi / dgh_n for the weight-gradient GEMMs.
 //
 //   fp32 mode: v_mfma_f32_16x16x4_f32, W_hh streamed from L2 every step (480 KB fp32 does not fit a CU)
-//   bf16 mode: v_mfma_f32_16x16x32_bf16, W_hh fragments resident in VGPRs for the whole sequence
+//   bf16 mode: v_mfma_f32_16x16x32_bf16, W_hh fragments resident in VGPRs/AGPRs for the whole sequence
+//              (336 registers per lane), h / dgh exchanged through a ping-pong bf16 LDS image: ONE
+//              barrier per timestep.
+//
+// Saved for backward, per row: gates4 [R][224][4] = (r, z, n, gh_n) interleaved (one 16-byte access
+// per owned element), hs [R][224], hprev [R][224] (= h_{t-1}, the B operand of the dW_hh GEMM).
 #include "common.h"
 
 namespace {
 
 constexpr int MB = 16;             // users per workgroup (MFMA M)
 constexpr int NJT = SV_HP / 16;    // 14 hidden-unit tiles of 16
-constexpr int HLD = SV_HP + 4;     // LDS row stride (floats) of the h image
-constexpr int GLD = SV_G + 4;      // LDS row stride (floats) of the dgh image
+constexpr int HLD = SV_HP + 4;     // fp32 LDS row stride (floats) of the h image
+constexpr int GLD = SV_G + 4;      // fp32 LDS row stride (floats) of the dgh image
+constexpr int HLDB = SV_HP + 8;    // bf16 LDS row stride (elements) of the h image   (464 B rows)
+constexpr int GLDB = SV_G + 8;     // bf16 LDS row stride (elements) of the dgh image (1360 B rows)
 
 struct GruArgs {
     const float* gi;      // [R][672]   (fwd)   input-side pre-activations incl. b_ih
@@ -27,13 +37,48 @@ struct GruArgs {
     const float* bhh;     // [672]
     const int* row_off;   // [Tmax+1]
     const int* nact;      // [Tmax]
-    float* hs;            // [R][224]  hidden states (fwd out / bwd in)
-    float* gates;         // [R][5][224]  r, z, n, gh_n, h_{t-1}  (fwd out / bwd in)
+    float* hs;            // [R][224]     h_t        (fwd out)
+    float* hprev;         // [R][224]     h_{t-1}    (fwd out / bwd in)
+    float* gates4;        // [R][224][4]  r, z, n, gh_n  (fwd out / bwd in)
     const float* dhs;     // [R][224]  (bwd in) dL/dh_t from the encoder side
-    float* dgi;           // [R][672]  (bwd out)
-    float* dgh;           // [R][672]  (bwd out)
+    float* dgi;           // [R][672]  (bwd out) d/d(gi) = (dr_pre, dz_pre, dn_pre)
+    float* dghn;          // [R][224]  (bwd out) d/d(gh_n) = dn_pre * r      (dgh_r = dgi_r, dgh_z = dgi_z)
     int B, Tmax;
 };
+
+// forward gate math for one owned element; returns h_t
+template <bool FAST = false>
+__device__ __forceinline__ float gate_fwd(const GruArgs& a, size_t row, int j, float gir, float giz, float gin,
+                                          float ghr, float ghz, float ghn, float hp) {
+    const float rg = FAST ? sv_sigmoid_fast(gir + ghr) : sv_sigmoid(gir + ghr);
+    const float zg = FAST ? sv_sigmoid_fast(giz + ghz) : sv_sigmoid(giz + ghz);
+    const float ng = FAST ? sv_tanh_fast(gin + rg * ghn) : tanhf(gin + rg * ghn);
+    const float hn = (1.0f - zg) * ng + zg * hp;
+    a.hs[row * SV_HP + j] = hn;
+    a.hprev[row * SV_HP + j] = hp;
+    *reinterpret_cast<float4*>(a.gates4 + (row * SV_HP + j) * 4) = make_float4(rg, zg, ng, ghn);
+    return hn;
+}
+
+// backward gate math for one owned element: d = dL/dh_t (total).  Writes dgi/dghn, returns the three
+// dgh values through refs and d*z (the direct carry into dh_{t-1}).
+__device__ __forceinline__ float gate_bwd(const GruArgs& a, size_t row, int j, float d, float4 gt, float hp,
+                                          float& drp, float& dzp, float& dnr) {
+    const float rg = gt.x, zg = gt.y, ng = gt.z, ghn = gt.w;
+    const float dn = d * (1.0f - zg);
+    const float dzg = d * (hp - ng);
+    const float dnp = dn * (1.0f - ng * ng);
+    const float drg = dnp * ghn;
+    dzp = dzg * zg * (1.0f - zg);
+    drp = drg * rg * (1.0f - rg);
+    dnr = dnp * rg;
+    float* o1 = a.dgi + row * SV_G;
+    o1[j] = drp;
+    o1[SV_HP + j] = dzp;
+    o1[2 * SV_HP + j] = dnp;
+    a.dghn[row * SV_HP + j] = dnr;
+    return d * zg;
+}
 
 // ------------------------------------------------------------------------------------------------
 // fp32 forward
@@ -94,7 +139,22 @@ __global__ __launch_bounds__(256) void gru_fwd_f32_kernel(GruArgs a) {
         }
         __syncthreads();  // every wave has finished reading h_{t-1} from LDS
 
-        // gate math: lane owns hidden unit j = 16*jt + ln for users m = 4*lk + r
+        // gate math.  Loads are unconditional (row clamped to an active one) and issued for all owned
+        // elements first: a load inside the per-element `if` would serialise one memory round trip per element.
+        float gv[4][4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jt = wave + 4 * q;
+            if (jt < NJT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 4 * lk + r;
+                    const float* gp = a.gi + (size_t)(rbase + ((u0 + m < na) ? m : 0)) * SV_G + 16 * jt + ln;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) gv[q][r][g] = gp[g * SV_HP];
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int jt = wave + 4 * q;
@@ -106,21 +166,9 @@ __global__ __launch_bounds__(256) void gru_fwd_f32_kernel(GruArgs a) {
                     const int m = 4 * lk + r;
                     if (u0 + m < na) {
                         const size_t row = (size_t)(rbase + m);
-                        const float* gp = a.gi + row * SV_G;
-                        const float ghn = acc[q][2][r] + bn;
-                        const float rg = sv_sigmoid(gp[j] + acc[q][0][r] + br);
-                        const float zg = sv_sigmoid(gp[SV_HP + j] + acc[q][1][r] + bz);
-                        const float ng = tanhf(gp[2 * SV_HP + j] + rg * ghn);
-                        const float hp = hreg[q][r];
-                        const float hn = (1.0f - zg) * ng + zg * hp;
+                        const float hn = gate_fwd(a, row, j, gv[q][r][0], gv[q][r][1], gv[q][r][2],
+                                                  acc[q][0][r] + br, acc[q][1][r] + bz, acc[q][2][r] + bn, hreg[q][r]);
                         hreg[q][r] = hn;
-                        a.hs[row * SV_HP + j] = hn;
-                        float* gs = a.gates + row * (5 * SV_HP);
-                        gs[4 * SV_HP + j] = hp;
-                        gs[j] = rg;
-                        gs[SV_HP + j] = zg;
-                        gs[2 * SV_HP + j] = ng;
-                        gs[3 * SV_HP + j] = ghn;
                         h_lds[m * HLD + j] = hn;
                     }
                 }
@@ -152,6 +200,22 @@ __global__ __launch_bounds__(256) void gru_bwd_f32_kernel(GruArgs a) {
         const int na = a.nact[t];
         const int rbase = a.row_off[t] + u0;
         float carry[4][4];
+        float4 sg[4][4];
+        float shp[4][4], sdh[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jt = wave + 4 * q;
+            if (jt < NJT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 4 * lk + r;
+                    const size_t e = (size_t)(rbase + ((u0 + m < na) ? m : 0)) * SV_HP + 16 * jt + ln;
+                    sg[q][r] = *reinterpret_cast<const float4*>(a.gates4 + e * 4);
+                    shp[q][r] = a.hprev[e];
+                    sdh[q][r] = a.dhs[e];
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int jt = wave + 4 * q;
@@ -160,26 +224,11 @@ __global__ __launch_bounds__(256) void gru_bwd_f32_kernel(GruArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = 4 * lk + r;
-                    float drp = 0.f, dzp = 0.f, dnp = 0.f, dnr = 0.f;
+                    float drp = 0.f, dzp = 0.f, dnr = 0.f;
                     carry[q][r] = 0.f;
                     if (u0 + m < na) {
                         const size_t row = (size_t)(rbase + m);
-                        const float* gs = a.gates + row * (5 * SV_HP);
-                        const float rg = gs[j], zg = gs[SV_HP + j], ng = gs[2 * SV_HP + j], ghn = gs[3 * SV_HP + j];
-                        const float hprev = gs[4 * SV_HP + j];
-                        const float d = dh[q][r] + a.dhs[row * SV_HP + j];
-                        const float dn = d * (1.0f - zg);
-                        const float dzg = d * (hprev - ng);
-                        dnp = dn * (1.0f - ng * ng);
-                        const float drg = dnp * ghn;
-                        dzp = dzg * zg * (1.0f - zg);
-                        drp = drg * rg * (1.0f - rg);
-                        dnr = dnp * rg;
-                        carry[q][r] = d * zg;
-                        float* o1 = a.dgi + row * SV_G;
-                        float* o2 = a.dgh + row * SV_G;
-                        o1[j] = drp; o1[SV_HP + j] = dzp; o1[2 * SV_HP + j] = dnp;
-                        o2[j] = drp; o2[SV_HP + j] = dzp; o2[2 * SV_HP + j] = dnr;
+                        carry[q][r] = gate_bwd(a, row, j, dh[q][r] + sdh[q][r], sg[q][r], shp[q][r], drp, dzp, dnr);
                     }
                     g_lds[m * GLD + j] = drp;
                     g_lds[m * GLD + SV_HP + j] = dzp;
@@ -221,39 +270,300 @@ __global__ __launch_bounds__(256) void gru_bwd_f32_kernel(GruArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 kernels: weights resident in registers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 load_w8(const float* p) {
+    const float4 lo = *reinterpret_cast<const float4*>(p);
+    const float4 hi = *reinterpret_cast<const float4*>(p + 4);
+    bf16x8 v;
+    v[0] = (short)sv_f2bf(lo.x); v[1] = (short)sv_f2bf(lo.y); v[2] = (short)sv_f2bf(lo.z); v[3] = (short)sv_f2bf(lo.w);
+    v[4] = (short)sv_f2bf(hi.x); v[5] = (short)sv_f2bf(hi.y); v[6] = (short)sv_f2bf(hi.z); v[7] = (short)sv_f2bf(hi.w);
+    return v;
+}
+
+// Register budget: a wave that owns 4 hidden tiles would need 336 registers for its W_hh fragments alone;
+// with the per-step prefetch (gi / saved gates) that spills.  So every wave keeps THREE tiles in registers
+// (252) and the fourth tile of waves 0 and 1 lives in LDS in fragment order (lane-linear 16-byte reads,
+// conflict-free): 2 waves x 21 fragments x 1 KiB = 42 KiB.
+constexpr int WL_FRAGS = 21;                       // fragments of the LDS-resident tile (fwd: 3 gates x 7; bwd: 21 k-steps)
+constexpr int WL_ELEMS = 2 * WL_FRAGS * 64 * 8;    // bf16 elements
+
+// Forward keeps only TWO tiles per wave in registers (168): the gate math (expf / tanhf expansions, the gi
+// prefetch, h state) needs the rest of the arch VGPRs.  LDS-resident forward tiles: waves 0,1 two each,
+// waves 2,3 one each = 6 tiles x 21 KiB = 126 KiB.
+constexpr int WLF_ELEMS = 6 * WL_FRAGS * 64 * 8;
+
+template <int NQ>  // number of hidden tiles this wave owns (4 for waves 0,1; 3 for waves 2,3)
+__device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned short* h_bf, unsigned short* w_lds,
+                                                  int wave, int lane) {
+    const int u0 = blockIdx.x * MB;
+    const int ln = lane & 15, lk = lane >> 4;
+    constexpr int KS = SV_HP / 32;  // 7 k-steps
+    constexpr int NR = 2;           // tiles in registers
+    constexpr int NL = NQ - NR;     // tiles in LDS
+
+    bf16x8 W[NR][3][KS];
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                W[q][g][s] = load_w8(a.whh + (size_t)(g * SV_HP + 16 * (wave + 4 * q) + ln) * SV_HP + 32 * s + 8 * lk);
+    const int slot = (NQ == 4) ? wave * 2 : 4 + (wave - 2);
+    unsigned short* wl = w_lds + (size_t)slot * (WL_FRAGS * 64 * 8) + lane * 8;
+#pragma unroll
+    for (int ql = 0; ql < NL; ++ql)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                *reinterpret_cast<bf16x8*>(wl + ((ql * 3 + g) * KS + s) * 512) =
+                    load_w8(a.whh + (size_t)(g * SV_HP + 16 * (wave + 4 * (NR + ql)) + ln) * SV_HP + 32 * s + 8 * lk);
+    float bias[NQ][3];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bias[q][g] = a.bhh[g * SV_HP + 16 * (wave + 4 * q) + ln];
+
+    float hreg[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hreg[q][r] = 0.f;
+
+    for (int t = 0; t < a.Tmax; ++t) {
+        const int na = a.nact[t];
+        if (na <= u0) break;
+        const int rbase = a.row_off[t] + u0;
+        const unsigned short* hcur = h_bf + (t & 1) * (MB * HLDB);
+        unsigned short* hnxt = h_bf + ((t + 1) & 1) * (MB * HLDB);
+
+        // input-side gates of this step: issued before the matmul so they land behind it
+        float gi[NQ][4][3];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * lk + r;
+                const bool act = (u0 + m) < na;
+                const float* gp = a.gi + (size_t)(rbase + (act ? m : 0)) * SV_G + 16 * (wave + 4 * q) + ln;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gi[q][r][g] = gp[g * SV_HP];
+            }
+
+        f32x4 acc[NQ][3];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[q][g] = (f32x4){bias[q][g], bias[q][g], bias[q][g], bias[q][g]};
+        if (t > 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 A = *reinterpret_cast<const bf16x8*>(hcur + ln * HLDB + 32 * s + 8 * lk);
+#pragma unroll
+                for (int q = 0; q < NR; ++q)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[q][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, W[q][g][s], acc[q][g], 0, 0, 0);
+#pragma unroll
+                for (int ql = 0; ql < NL; ++ql)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wl + ((ql * 3 + g) * KS + s) * 512);
+                        acc[NR + ql][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, wv, acc[NR + ql][g], 0, 0, 0);
+                    }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int j = 16 * (wave + 4 * q) + ln;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * lk + r;
+                if (u0 + m < na) {
+                    const size_t row = (size_t)(rbase + m);
+                    const float hn = gate_fwd<true>(a, row, j, gi[q][r][0], gi[q][r][1], gi[q][r][2], acc[q][0][r],
+                                              acc[q][1][r], acc[q][2][r], hreg[q][r]);
+                    hreg[q][r] = hn;
+                    hnxt[m * HLDB + j] = sv_f2bf(hn);
+                }
+            }
+        }
+        __syncthreads();  // h_t published (ping-pong image: the next step writes the other buffer)
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void gru_fwd_bf16_kernel(GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_f[];
+    unsigned short* w_lds = smem_f;                // 6 tiles x [21][64][8]
+    unsigned short* h_bf = smem_f + WLF_ELEMS;     // [2][MB][HLDB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * MB * HLDB; i += 256) h_bf[i] = 0;
+    __syncthreads();
+    if (wave < 2)
+        gru_fwd_bf16_body<4>(a, h_bf, w_lds, wave, lane);
+    else
+        gru_fwd_bf16_body<3>(a, h_bf, w_lds, wave, lane);
+}
+
+template <int NQ>
+__device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned short* g_bf, unsigned short* w_lds,
+                                                  int wave, int lane) {
+    const int u0 = blockIdx.x * MB;
+    const int ln = lane & 15, lk = lane >> 4;
+    constexpr int KS = SV_G / 32;  // 21 k-steps
+
+    // B operand of dh_{t-1} = dgh W_hh: B[k = gate column c][n = hidden j'] = W_hh[c][j'] = whh_t[j'][c]
+    bf16x8 W[3][KS];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            W[q][s] = load_w8(a.whh + (size_t)(16 * (wave + 4 * q) + ln) * SV_G + 32 * s + 8 * lk);
+    unsigned short* wl = w_lds + (size_t)wave * (WL_FRAGS * 64 * 8) + lane * 8;
+    if (NQ == 4) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            *reinterpret_cast<bf16x8*>(wl + s * 512) =
+                load_w8(a.whh + (size_t)(16 * (wave + 12) + ln) * SV_G + 32 * s + 8 * lk);
+    }
+
+    int Tw = 0;
+    while (Tw < a.Tmax && a.nact[Tw] > u0) ++Tw;
+
+    float dh[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[q][r] = 0.f;
+
+    for (int t = Tw - 1; t >= 0; --t) {
+        const int na = a.nact[t];
+        const int rbase = a.row_off[t] + u0;
+        unsigned short* gcur = g_bf + (t & 1) * (MB * GLDB);
+        float carry[NQ][4];
+        float4 sg[NQ][4];
+        float shp[NQ][4], sdh[NQ][4];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * lk + r;
+                const size_t e = (size_t)(rbase + ((u0 + m < na) ? m : 0)) * SV_HP + 16 * (wave + 4 * q) + ln;
+                sg[q][r] = *reinterpret_cast<const float4*>(a.gates4 + e * 4);
+                shp[q][r] = a.hprev[e];
+                sdh[q][r] = a.dhs[e];
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int j = 16 * (wave + 4 * q) + ln;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * lk + r;
+                float drp = 0.f, dzp = 0.f, dnr = 0.f;
+                carry[q][r] = 0.f;
+                if (u0 + m < na) {
+                    const size_t row = (size_t)(rbase + m);
+                    carry[q][r] = gate_bwd(a, row, j, dh[q][r] + sdh[q][r], sg[q][r], shp[q][r], drp, dzp, dnr);
+                }
+                gcur[m * GLDB + j] = sv_f2bf(drp);
+                gcur[m * GLDB + SV_HP + j] = sv_f2bf(dzp);
+                gcur[m * GLDB + 2 * SV_HP + j] = sv_f2bf(dnr);
+            }
+        }
+        __syncthreads();  // dgh_t published (ping-pong: step t-1 writes the other buffer)
+        if (t > 0) {
+            f32x4 acc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s0 = 0; s0 < KS; s0 += 7) {
+                bf16x8 A[7];
+#pragma unroll
+                for (int s = 0; s < 7; ++s)
+                    A[s] = *reinterpret_cast<const bf16x8*>(gcur + ln * GLDB + 32 * (s0 + s) + 8 * lk);
+#pragma unroll
+                for (int s = 0; s < 7; ++s) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], W[q][s0 + s], acc[q], 0, 0, 0);
+                    if (NQ == 4) {
+                        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wl + (s0 + s) * 512);
+                        acc[NQ - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], wv, acc[NQ - 1], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[q][r] = carry[q][r] + acc[q][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void gru_bwd_bf16_kernel(GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_b[];
+    unsigned short* w_lds = smem_b;                // [2][21][64][8]
+    unsigned short* g_bf = smem_b + WL_ELEMS;      // [2][MB][GLDB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave < 2)
+        gru_bwd_bf16_body<4>(a, g_bf, w_lds, wave, lane);
+    else
+        gru_bwd_bf16_body<3>(a, g_bf, w_lds, wave, lane);
+}
+
 }  // namespace
 
 static int check_gru(const GruArgs& a, bool bwd) {
-    SV_CHECK_ARG(a.whh && a.row_off && a.nact && a.hs && a.gates, "svae_gru: null pointer");
+    SV_CHECK_ARG(a.whh && a.row_off && a.nact && a.hprev && a.gates4, "svae_gru: null pointer");
     SV_CHECK_ARG(a.B > 0 && a.Tmax > 0, "svae_gru: empty batch (B=%d Tmax=%d)", a.B, a.Tmax);
-    if (!bwd) SV_CHECK_ARG(a.gi && a.bhh, "svae_gru_fwd: null pointer");
-    if (bwd) SV_CHECK_ARG(a.dhs && a.dgi && a.dgh, "svae_gru_bwd: null pointer");
+    if (!bwd) SV_CHECK_ARG(a.gi && a.bhh && a.hs, "svae_gru_fwd: null pointer");
+    if (bwd) SV_CHECK_ARG(a.dhs && a.dgi && a.dghn, "svae_gru_bwd: null pointer");
     return 0;
 }
 
 // Reference interface replaced: nn.GRU forward inside Model.forward (nb:759).
 extern "C" int svae_gru_fwd(const float* gi, const float* whh, const float* bhh, const int* row_off,
-                            const int* nact, int B, int Tmax, float* hs, float* gates, int prec, void* stream) {
-    GruArgs a{gi, whh, bhh, row_off, nact, hs, gates, nullptr, nullptr, nullptr, B, Tmax};
+                            const int* nact, int B, int Tmax, float* hs, float* hprev, float* gates4, int prec,
+                            void* stream) {
+    GruArgs a{gi, whh, bhh, row_off, nact, hs, hprev, gates4, nullptr, nullptr, nullptr, B, Tmax};
     if (int e = check_gru(a, false)) return e;
-    SV_CHECK_ARG(prec == 0, "svae_gru_fwd: prec %d not built", prec);
+    SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gru_fwd: bad prec %d", prec);
     dim3 grid((B + MB - 1) / MB);
-    hipLaunchKernelGGL(gru_fwd_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (prec == 0) {
+        hipLaunchKernelGGL(gru_fwd_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        const int lds = (WLF_ELEMS + 2 * MB * HLDB) * sizeof(unsigned short);   // 144 KiB of the CU's 160
+        hipError_t e = hipFuncSetAttribute((const void*)gru_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return svae_fail((int)e, "svae_gru_fwd: LDS attribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(gru_fwd_bf16_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
     SV_LAUNCH_CHECK();
     return 0;
 }
 
 // Reference interface replaced: autograd through nn.GRU at loss.backward() (nb:1205).
 // whh_t is W_hh transposed, [224][672].
-extern "C" int svae_gru_bwd(const float* dhs, const float* hs, const float* gates, const float* whh_t,
-                            const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dgh,
+extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
+                            const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dghn,
                             int prec, void* stream) {
-    GruArgs a{nullptr, whh_t, nullptr, row_off, nact, const_cast<float*>(hs), const_cast<float*>(gates),
-              dhs, dgi, dgh, B, Tmax};
+    GruArgs a{nullptr, whh_t, nullptr, row_off, nact, nullptr, const_cast<float*>(hprev),
+              const_cast<float*>(gates4), dhs, dgi, dghn, B, Tmax};
     if (int e = check_gru(a, true)) return e;
-    SV_CHECK_ARG(prec == 0, "svae_gru_bwd: prec %d not built", prec);
+    SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gru_bwd: bad prec %d", prec);
     dim3 grid((B + MB - 1) / MB);
-    hipLaunchKernelGGL(gru_bwd_f32_kernel, grid, dim3(256), MB * GLD * sizeof(float), (hipStream_t)stream, a);
+    if (prec == 0) {
+        hipLaunchKernelGGL(gru_bwd_f32_kernel, grid, dim3(256), MB * GLD * sizeof(float), (hipStream_t)stream, a);
+    } else {
+        const int lds = (WL_ELEMS + 2 * MB * GLDB) * sizeof(unsigned short);
+        hipError_t e = hipFuncSetAttribute((const void*)gru_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return svae_fail((int)e, "svae_gru_bwd: LDS attribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(gru_bwd_bf16_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
     SV_LAUNCH_CHECK();
     return 0;
 }

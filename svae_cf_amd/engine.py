@@ -35,7 +35,7 @@ class SVAEEngine:
         self.layout = ParamLayout(total_items)
         self.I, self.IP = self.layout.I, self.layout.IP
         self.prec = prec
-        self.gru_prec = 0              # bf16 GRU kernels not built yet: recurrence stays fp32
+        self.gru_prec = prec
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
         n = self.layout.total
         f32 = dict(device=self.device, dtype=torch.float32)
@@ -83,8 +83,8 @@ class SVAEEngine:
             return
         cap = int(R * 1.25) + 64
         f32 = dict(device=self.device, dtype=torch.float32)
-        shapes = dict(emb=E, gi=G, hs=HP, gates=5 * HP, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
-                      logits=self.IP, dz=L, dtmp=2 * L, dd1=DP, denc=DP, dhs=HP, dgi=G, dgh=G, demb=E,
+        shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dghn=HP, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
+                      logits=self.IP, dz=L, dtmp=2 * L, dd1=DP, denc=DP, dhs=HP, dgi=G, demb=E,
                       kl_row=1, nll_row=1, lse=1)
         self.ws = {k: torch.empty(cap * w, **f32) for k, w in shapes.items()}
         self.cap = cap
@@ -147,7 +147,7 @@ class SVAEEngine:
         ev = self._tic("gru_fwd")
         _lib.call("svae_gru_fwd", w["gi"].data_ptr(), self.P("gru.weight_hh_l0").data_ptr(),
                   self.P("gru.bias_hh_l0").data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(),
-                  plan.B, plan.Tmax, w["hs"].data_ptr(), w["gates"].data_ptr(), self.gru_prec, st)
+                  plan.B, plan.Tmax, w["hs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(), self.gru_prec, st)
         self._toc("gru_fwd", ev)
         self._gemm(w["hs"], self.P("encoder.linear1.weight"), w["enc"], R, DP, HP, HP, HP, DP, 0, 0,
                    bias=self.P("encoder.linear1.bias"), act=1)
@@ -218,13 +218,17 @@ class SVAEEngine:
         # GRU (BPTT)
         _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
         ev = self._tic("gru_bwd")
-        _lib.call("svae_gru_bwd", w["dhs"].data_ptr(), w["hs"].data_ptr(), w["gates"].data_ptr(),
+        _lib.call("svae_gru_bwd", w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
                   self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
-                  w["dgi"].data_ptr(), w["dgh"].data_ptr(), self.gru_prec, st)
+                  w["dgi"].data_ptr(), w["dghn"].data_ptr(), self.gru_prec, st)
         self._toc("gru_bwd", ev)
-        hprev = w["gates"][4 * HP:]          # plane 4 of [R][5][224], row stride 5*224
-        self._wgrad(w["dgh"], hprev, self.Gv("gru.weight_hh_l0"), R, G, HP, G, 5 * HP)
-        self._colsum(w["dgh"], self.Gv("gru.bias_hh_l0"), R, G, G)
+        # dgh = (dgi_r, dgi_z, dghn): W_hh rows of gates r,z take dgi's first 448 columns, gate n takes dghn
+        gwhh = self.Gv("gru.weight_hh_l0").view(-1)
+        gbhh = self.Gv("gru.bias_hh_l0").view(-1)
+        self._wgrad(w["dgi"], w["hprev"], gwhh, R, 2 * HP, HP, G, HP)
+        self._wgrad(w["dghn"], w["hprev"], gwhh[2 * HP * HP:], R, HP, HP, HP, HP)
+        self._colsum(w["dgi"], gbhh, R, 2 * HP, G)
+        self._colsum(w["dghn"], gbhh[2 * HP:], R, HP, HP)
         self._wgrad(w["dgi"], w["emb"], self.Gv("gru.weight_ih_l0"), R, G, E, G, E)
         self._colsum(w["dgi"], self.Gv("gru.bias_ih_l0"), R, G, G)
         self._bucket(2)
