@@ -58,7 +58,7 @@ def main():
     rng = np.random.default_rng(98765)
     batches = synth.bucketed_batches([len(u) for u in users], B, rng)
     mine = [batches[i] for i in range(rank, len(batches) // world * world, world)]
-    plans = [S.build_plan([users[i] for i in idx], 4, user_keys=idx, device=dev) for idx in mine]
+    plans = [S.build_plan([users[i] for i in idx], 4, user_keys=idx, device=dev, total_items=I) for idx in mine]
     rows = float(np.mean([p.R for p in plans]))
 
     prec = S.PREC_BF16 if args.prec == "bf16" else S.PREC_FP32
@@ -88,7 +88,7 @@ def main():
     for _ in range(args.warmup):
         eng.train_step(plans[step % len(plans)], 0.01, seed=1234)
         step += 1
-    tags = ["proj_fwd", "proj_dw", "proj_dx", "softmax_nll", "gru_fwd", "gru_bwd"]
+    tags = ["proj_fwd", "proj_bwd", "proj_dw", "proj_dx", "softmax_nll", "gru_fwd", "gru_bwd"]
     eng.prof = {t: [] for t in tags}
     barrier()
     t0 = time.perf_counter()

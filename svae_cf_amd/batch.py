@@ -22,22 +22,26 @@ class BatchPlan:
 
     __slots__ = ("B", "R", "Tmax", "K", "order", "lengths", "x", "tgt", "w_nll", "w_kl", "row_off",
                  "nact", "last_row", "perm", "seg_off", "seg_item", "nseg", "row_key", "seen",
-                 "seen_off", "row_of", "device")
+                 "seen_off", "row_of", "device", "occ_off", "occ_row", "total_items")
 
     def to(self, device):
         for name in ("x", "tgt", "w_nll", "w_kl", "row_off", "nact", "last_row", "perm", "seg_off",
-                     "seg_item", "row_key", "seen", "seen_off"):
-            setattr(self, name, getattr(self, name).to(device, non_blocking=True))
+                     "seg_item", "row_key", "seen", "seen_off", "occ_off", "occ_row"):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(self, name, v.to(device, non_blocking=True))
         self.device = device
         return self
 
 
-def build_plan(users, next_k, user_keys=None, device=None, pin=False):
+def build_plan(users, next_k, user_keys=None, device=None, pin=False, total_items=None):
     """users: list of 1-D int arrays (chronological item ids, len >= 2).
 
     next_k: number of following items that are targets of a timestep (reference
     ``hyper_params['next_k']``; ``predict_next`` is 1, ``postfix`` is any value >= max length).
     user_keys: int64 id per user for the counter-based noise stream (defaults to position).
+    total_items: catalogue size; when given, the plan also carries the target occurrences grouped by
+    item (``occ_off [I+1]``, ``occ_row``) that the fused projection backward needs for dL/dW3.
     """
     B = len(users)
     if B == 0:
@@ -111,6 +115,15 @@ def build_plan(users, next_k, user_keys=None, device=None, pin=False):
     p.row_off, p.nact, p.last_row = t(row_off), t(nact), t(last_row)
     p.perm, p.seg_off, p.seg_item = t(perm), t(seg_off), t(seg_item)
     p.row_key, p.seen, p.seen_off = t(row_key), t(seen), t(seen_off)
+    p.total_items = total_items
+    p.occ_off = p.occ_row = None
+    if total_items is not None:
+        rr, kk = np.nonzero(tgt >= 0)
+        it = tgt[rr, kk]
+        o = np.argsort(it, kind="stable")
+        occ_off = np.zeros(total_items + 1, dtype=np.int32)
+        np.cumsum(np.bincount(it, minlength=total_items), out=occ_off[1:])
+        p.occ_off, p.occ_row = t(occ_off), t(rr[o].astype(np.int32))
     if device is not None:
         p.to(device)
     return p

@@ -53,6 +53,10 @@ class SVAEEngine:
         self.colparts = torch.zeros(64 * max(self.IP, G), **f32)
         self._plan = None
         self._anneal = 0.0
+        # fused projection + log-softmax + NLL (never materialises logits): bf16 MFMA mode only
+        self.fused = (prec == PREC_BF16)
+        self.IPAD = (self.I + 63) // 64 * 64
+        self.w3b = self.w3tb = None
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.prof = None               # dict tag -> list of (start, end) torch.cuda.Event pairs
 
@@ -86,8 +90,25 @@ class SVAEEngine:
         shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dghn=HP, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
                       logits=self.IP, dz=L, dtmp=2 * L, dd1=DP, denc=DP, dhs=HP, dgi=G, demb=E,
                       kl_row=1, nll_row=1, lse=1)
+        if self.fused:
+            shapes["logits"] = 0
         self.ws = {k: torch.empty(cap * w, **f32) for k, w in shapes.items()}
         self.cap = cap
+        if self.fused:
+            bf = dict(device=self.device, dtype=torch.bfloat16)
+            capp = (cap + 63) // 64 * 64
+            self.capp = capp
+            self.ws["h2b"] = torch.zeros(capp * DP, **bf)
+            self.ws["h2tb"] = torch.zeros(DP * capp, **bf)
+            self.ws["kx_rows"] = torch.zeros(capp, **f32)
+            self.ws["ky_rows"] = torch.zeros(capp, **f32)
+            self.ws["part"] = torch.zeros(8 * capp * 2, **f32)
+            self.ws["pslabs"] = torch.empty(8 * max(capp, self.IPAD) * DP, **f32)
+            if self.w3b is None:
+                self.w3b = torch.zeros(self.IPAD * DP, **bf)
+                self.w3tb = torch.zeros(DP * self.IPAD, **bf)
+                self.ky_items = torch.zeros(self.IPAD, **f32)
+                self.kx_items = torch.zeros(self.IPAD, **f32)
 
     def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, al, bl, bias=None, act=0, aux=None, ldaux=0,
               nsplit=1, slab_stride=0, tag=None):
@@ -164,6 +185,21 @@ class SVAEEngine:
                   w["kl_row"].data_ptr(), R, st)
         self._gemm(w["z"], self.P("decoder.linear1.weight"), w["d1"], R, DP, L, L, L, DP, 0, 0,
                    bias=self.P("decoder.linear1.bias"), act=1)
+        if self.fused and want_loss:
+            self._proj_prepare(R)
+            Rp = (R + 63) // 64 * 64
+            ev = self._tic("proj_fwd")
+            _lib.call("svae_proj_nll_fwd", w["h2b"].data_ptr(), self.w3b.data_ptr(), self.ky_items.data_ptr(),
+                      w["d1"].data_ptr(), self.P("decoder.linear2.weight").data_ptr(),
+                      self.P("decoder.linear2.bias").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
+                      R, Rp, self.I, plan.K, w["part"].data_ptr(), w["nll_row"].data_ptr(), w["lse"].data_ptr(),
+                      w["kx_rows"].data_ptr(), w["ky_rows"].data_ptr(), st)
+            self._toc("proj_fwd", ev)
+            _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
+                      plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
+            return self.loss_out
+        if self.fused:
+            raise RuntimeError("dense logits are not kept in fused mode: use dense_logits()")
         self._gemm(w["d1"], self.P("decoder.linear2.weight"), w["logits"], R, self.I, DP, DP, DP, self.IP, 0, 0,
                    bias=self.P("decoder.linear2.bias"), tag="proj_fwd")
         if want_loss:
@@ -175,6 +211,34 @@ class SVAEEngine:
             _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
         return self.loss_out
+
+    def _proj_prepare(self, R):
+        """bf16 operand copies for the fused projection kernels (W3 changes every step)."""
+        w, st = self.ws, _stream()
+        Rp = (R + 63) // 64 * 64
+        _lib.call("svae_proj_prep", w["d1"].data_ptr(), w["h2b"].data_ptr(), w["h2tb"].data_ptr(), R, Rp, Rp,
+                  D, st)                                     # column 150 := 1.0 (bias-gradient column)
+        _lib.call("svae_proj_prep", self.P("decoder.linear2.weight").data_ptr(), self.w3b.data_ptr(),
+                  self.w3tb.data_ptr(), self.I, self.IPAD, self.IPAD, -1, st)
+        _lib.call("svae_proj_bias_consts", self.P("decoder.linear2.bias").data_ptr(), self.ky_items.data_ptr(),
+                  self.kx_items.data_ptr(), self.I, self.IPAD, st)
+
+    def dense_logits(self, rows_idx=None):
+        """Dense logits [n, I] for all rows of the last forward (rows_idx None) or a gathered subset
+        (int32 device tensor).  This is the Model.forward / evaluate() surface; training never calls it."""
+        plan, st = self._plan, _stream()
+        f32 = dict(device=self.device, dtype=torch.float32)
+        if rows_idx is None:
+            n, src = plan.R, self.ws["d1"]
+        else:
+            n = int(rows_idx.numel())
+            src = torch.empty(n * DP, **f32)
+            _lib.call("svae_gather_rows", self.ws["d1"].data_ptr(), rows_idx.data_ptr(), src.data_ptr(),
+                      n, DP, DP, DP, st)
+        out = torch.empty(n * self.IP, **f32)
+        self._gemm(src, self.P("decoder.linear2.weight"), out, n, self.I, DP, DP, DP, self.IP, 0, 0,
+                   bias=self.P("decoder.linear2.bias"))
+        return out.view(n, self.IP)
 
     def logits_rows(self, R):
         return self.ws["logits"][:R * self.IP].view(R, self.IP)[:, :self.I]
@@ -192,13 +256,27 @@ class SVAEEngine:
         R, I, IP = plan.R, self.I, self.IP
         w, st = self.ws, _stream()
         lay = self.layout
-        dl = w["logits"]
-        # decoder.linear2
-        self._gemm(dl, w["d1"], self.Gv("decoder.linear2.weight"), IP, DP, R, IP, DP, DP, 1, 1, tag="proj_dw")
-        self._colsum(dl, self.Gv("decoder.linear2.bias"), R, I, IP)
-        self._bucket(0)
-        self._gemm(dl, self.P("decoder.linear2.weight"), w["dd1"], R, DP, IP, IP, DP, DP, 0, 1,
-                   act=2, aux=w["d1"], ldaux=DP, tag="proj_dx")
+        if self.fused:
+            if plan.occ_off is None:
+                raise ValueError("fused mode needs build_plan(..., total_items=I)")
+            Rp = (R + 63) // 64 * 64
+            ev = self._tic("proj_bwd")
+            _lib.call("svae_proj_nll_bwd", w["h2b"].data_ptr(), w["h2tb"].data_ptr(), Rp, self.w3b.data_ptr(),
+                      self.w3tb.data_ptr(), self.IPAD, w["kx_rows"].data_ptr(), w["ky_rows"].data_ptr(),
+                      self.kx_items.data_ptr(), self.ky_items.data_ptr(), w["d1"].data_ptr(),
+                      self.P("decoder.linear2.weight").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
+                      plan.occ_off.data_ptr(), plan.occ_row.data_ptr(), R, I, IP, plan.K, w["pslabs"].data_ptr(),
+                      w["dd1"].data_ptr(), self.Gv("decoder.linear2.weight").data_ptr(),
+                      self.Gv("decoder.linear2.bias").data_ptr(), st)
+            self._toc("proj_bwd", ev)
+            self._bucket(0)
+        else:
+            dl = w["logits"]
+            self._gemm(dl, w["d1"], self.Gv("decoder.linear2.weight"), IP, DP, R, IP, DP, DP, 1, 1, tag="proj_dw")
+            self._colsum(dl, self.Gv("decoder.linear2.bias"), R, I, IP)
+            self._bucket(0)
+            self._gemm(dl, self.P("decoder.linear2.weight"), w["dd1"], R, DP, IP, IP, DP, DP, 0, 1,
+                       act=2, aux=w["d1"], ldaux=DP, tag="proj_dx")
         # decoder.linear1
         self._wgrad(w["dd1"], w["z"], self.Gv("decoder.linear1.weight"), R, DP, L, DP, L)
         self._colsum(w["dd1"], self.Gv("decoder.linear1.bias"), R, DP, DP)
@@ -268,12 +346,10 @@ class SVAEEngine:
         B, st = plan.B, _stream()
         k = int(min(topk, self.I))
         f32 = dict(device=self.device, dtype=torch.float32)
-        last = torch.empty(B * self.IP, **f32)
+        last = self.dense_logits(plan.last_row)          # [B, IP]: only the ranked rows are projected densely
         work = torch.empty(B * self.IP, **f32)
         idx = torch.empty(B * k, device=self.device, dtype=torch.int32)
         val = torch.empty(B * k, **f32)
-        _lib.call("svae_gather_rows", self.ws["logits"].data_ptr(), plan.last_row.data_ptr(), last.data_ptr(),
-                  B, self.IP, self.IP, self.IP, st)
         _lib.call("svae_masked_topk", last.data_ptr(), self.IP, plan.seen.data_ptr(), plan.seen_off.data_ptr(),
                   B, self.I, k, idx.data_ptr(), val.data_ptr(), work.data_ptr(), st)
-        return self.loss_out, idx.view(B, k), val.view(B, k), last.view(B, self.IP)[:, :self.I]
+        return self.loss_out, idx.view(B, k), val.view(B, k), last[:, :self.I]

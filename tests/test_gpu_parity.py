@@ -205,7 +205,7 @@ def test_bf16_mode_train_steps_vs_reference(golden_dir):
     eng.load_state_dict(_sd(O.make_params(I, seed)))
     losses = []
     for b, u in enumerate(g["order"], start=1):
-        plan = S.build_plan([g["items%d" % u]], 4, device="cuda")
+        plan = S.build_plan([g["items%d" % u]], 4, device="cuda", total_items=I)
         eps = torch.from_numpy(S.pack_rows(plan, [g["eps%d" % (b - 1)]], 64)).cuda()
         losses.append(float(eng.train_step(plan, O.anneal_for_batch(b), eps=eps)[0]))
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
@@ -224,7 +224,7 @@ def test_bf16_mode_larger_batch_vs_oracle():
     loss_ref, grads_ref = O.batch_loss_and_grads(p, users, epsl, 0.13, 4, np.float64)
     eng = _engine(I, prec=1)
     eng.load_state_dict(_sd(p))
-    plan = S.build_plan(users, 4, device="cuda")
+    plan = S.build_plan(users, 4, device="cuda", total_items=I)
     eps = torch.from_numpy(S.pack_rows(plan, epsl, 64)).cuda()
     out = eng.forward(plan, 0.13, eps=eps)
     eng.backward()

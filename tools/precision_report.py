@@ -30,11 +30,11 @@ for prec, pname in ((0, "fp32"), (1, "bf16")):
     I, seed, anneal = int(g["total_items"]), int(g["seed"]), float(g["anneal"])
     eng = S.SVAEEngine(I, prec=prec)
     eng.load_state_dict(sd(O.make_params(I, seed)))
-    plan = S.build_plan([g["u0_items"]], 4, device="cuda")
+    plan = S.build_plan([g["u0_items"]], 4, device="cuda", total_items=I)
     eps = torch.from_numpy(S.pack_rows(plan, [g["u0_eps"]], 64)).cuda()
     out = eng.forward(plan, anneal, eps=eps, want_grad=False)
     print(" logits l2 %.2e  mu %.2e  loss rel %.2e" % (
-        l2(eng.logits_rows(plan.R).cpu().numpy(), g["u0_dec_out"]),
+        l2(eng.dense_logits()[:, :I].cpu().numpy(), g["u0_dec_out"]),
         l2(eng.mu_logsigma(plan.R)[0].cpu().numpy(), g["u0_mu"]),
         abs(float(out[0]) - float(g["u0_loss"])) / float(g["u0_loss"])))
     eng.forward(plan, anneal, eps=eps)
@@ -48,7 +48,7 @@ for prec, pname in ((0, "fp32"), (1, "bf16")):
     eng.load_state_dict(sd(O.make_params(I, seed)))
     losses = []
     for b, u in enumerate(g["order"], start=1):
-        plan = S.build_plan([g["items%d" % u]], 4, device="cuda")
+        plan = S.build_plan([g["items%d" % u]], 4, device="cuda", total_items=I)
         eps = torch.from_numpy(S.pack_rows(plan, [g["eps%d" % (b - 1)]], 64)).cuda()
         losses.append(float(eng.train_step(plan, O.anneal_for_batch(b), eps=eps)[0]))
     print(" train 12 steps: max loss rel err %.2e" % np.max(np.abs(np.array(losses) - g["losses"]) / g["losses"]))
