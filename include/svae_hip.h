@@ -1,0 +1,125 @@
+/* svae_hip.h -- C-ABI of libsvae_hip.so: the MI355X (gfx950) kernels of the SVAE training / scoring step.
+ *
+ * Reference: noveens/svae_cf, main_svae.ipynb ("nb:N" = raw line N of that file).  The reference has
+ * no FFI of its own: its hot path is the PyTorch call sites listed in SURVEY.md section 2a.  Each
+ * entry point below names the reference call site(s) it replaces; INTEGRATION.md shows the ctypes
+ * binding a maintainer of the notebook would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - every function enqueues on the caller's hipStream_t (passed as void*), never allocates, never
+ *     frees and never synchronises: workspaces are arguments;
+ *   - returns 0 on success, < 0 for an argument error, > 0 = hipError_t of a failed launch;
+ *     svae_last_error() returns the message of the calling thread's last failure;
+ *   - fp32 row-major tensors; model dimensions are compile-time (hyper_params nb:82-85):
+ *       E = 256 item_embed_size, H = 200 rnn_size (padded HP = 224), D = 150 hidden_size (padded
+ *       DP = 160), L = 64 latent_size; gate columns G = 3*224 = 672 ordered (r, z, n) with gate g of
+ *       hidden unit j at column g*224 + j.  Pad rows / columns of weights are zero;
+ *   - a batch is TIME-MAJOR PACKED: users sorted by length (descending), nact[t] users are active at
+ *     timestep t, row_off[t] = first row of timestep t, R = row_off[Tmax] rows in total;
+ *   - prec: 0 = exact fp32 MFMA (v_mfma_f32_*_f32), 1 = bf16 MFMA with fp32 accumulation.
+ */
+#ifndef SVAE_HIP_H
+#define SVAE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- plumbing ------------------------------------------------------------------------------ */
+const char* svae_last_error(void);
+int svae_abi_version(void);
+int svae_check_device(void); /* 0 if the current device is gfx950 */
+
+/* ---- generic GEMM: C[M,N] = epi(sum_k A(m,k) B(k,n))  -------------------------------------------
+ * Replaces the nn.Linear call sites (addmm): Encoder.linear1 nb:694, Model.linear1 nb:738,
+ * Decoder.linear1 nb:708, Decoder.linear2 nb:710 (dense logits for the Model.forward surface), the
+ * GRU input GEMM inside nn.GRU nb:759, and their autograd GEMMs (nb:1205).
+ * a_layout 0: A stored [M][K]; 1: A stored [K][M].  b_layout 0: B stored [N][K]; 1: B stored [K][N].
+ * act 0 none, 1 tanh, 2 multiply by (1 - aux^2) (tanh backward).  nsplit > 1: split-K, split z writes
+ * C + z*slab_stride (no epilogue); reduce with svae_reduce_slabs. */
+int svae_gemm(const float* A, const float* B, float* C, const float* bias, const float* aux, int M, int N, int K,
+              int lda, int ldb, int ldc, int ldaux, int a_layout, int b_layout, int act, int prec, int nsplit,
+              long long slab_stride, void* stream);
+int svae_reduce_slabs(const float* slabs, float* out, long long n, int nsplit, long long slab_stride, void* stream);
+
+/* ---- item embedding ----------------------------------------------------------------------------
+ * svae_embed_fwd replaces self.item_embed(x) nb:756: out[r][:] = table[x[r]][:] (E = 256).
+ * svae_embed_bwd replaces the embedding backward of loss.backward() nb:1205 as a deterministic
+ * segmented sum: perm = rows sorted by item, segment s covers perm[seg_off[s]..seg_off[s+1]) and is
+ * written to gtable[seg_item[s]] (gtable zero-filled by the caller). */
+int svae_embed_fwd(const float* table, const int* x, float* out, int R, int I, void* stream);
+int svae_embed_bwd(const float* demb, const int* perm, const int* seg_off, const int* seg_item, float* gtable,
+                   int nseg, float scale, void* stream);
+
+/* ---- GRU recurrence, persistent over timesteps ---------------------------------------------------
+ * svae_gru_fwd replaces the recurrent part of nn.GRU (call nb:759, definition nb:724-727; h0 = 0).
+ * gi [R][672] = emb W_ih^T + b_ih (svae_gemm); whh [672][224], bhh [672].
+ * Outputs hs [R][224], hprev [R][224] (h_{t-1}), gates4 [R][224][4] = (r, z, n, gh_n).
+ * svae_gru_bwd replaces autograd through nn.GRU (nb:1205): whh_t = W_hh^T [224][672];
+ * dhs [R][224] in; dgi [R][672] = d/d gi, dghn [R][224] = d/d gh_n out. */
+int svae_gru_fwd(const float* gi, const float* whh, const float* bhh, const int* row_off, const int* nact, int B,
+                 int Tmax, float* hs, float* hprev, float* gates4, int prec, void* stream);
+int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t, const int* row_off,
+                 const int* nact, int B, int Tmax, float* dgi, float* dghn, int prec, void* stream);
+
+/* ---- latent: reparameterisation + KL ---------------------------------------------------------------
+ * Replaces Model.sample_latent nb:734-750 and the KL term of VAELoss.forward nb:797.
+ * tmp [R][128] = (mu | log_sigma); z = mu + exp(log_sigma) * eps; kl_row[r] = sum_64 0.5(-ls+exp(ls)+mu^2-1).
+ * Backward: dtmp = (dz + a*w_kl[r]*mu | dz*exp(ls)*eps + a*w_kl[r]*0.5*(exp(ls)-1)), a = anneal. */
+int svae_latent_fwd(const float* tmp, const float* eps, float* z, float* kl_row, int R, void* stream);
+int svae_latent_bwd(const float* tmp, const float* eps, const float* dz, const float* w_kl, float anneal,
+                    float* dtmp, int R, void* stream);
+/* Replaces np.random.normal(0,1,size) nb:744 by Philox4x32-10 + Box-Muller keyed by (seed, step, row_key[r], col). */
+int svae_philox_normal(float* out, const long long* row_key, int R, unsigned long long seed, unsigned step,
+                       void* stream);
+
+/* ---- loss over materialised logits (fp32 path) ------------------------------------------------------
+ * Replaces F.log_softmax nb:802 + likelihood nb:805-808 (+ their gradient when write_grad != 0:
+ * logits are overwritten by w_nll[r] * (n_r softmax - y)).  tgt [R][K] int32, -1 = padding. */
+int svae_softmax_nll(float* logits, const int* tgt, const float* w_nll, float* nll_row, float* lse, int R, int I,
+                     int ldI, int K, int write_grad, void* stream);
+/* out3 = {sum_r w_nll nll_row + anneal * sum_r w_kl kl_row, likelihood part, KL part}  (VAELoss nb:810) */
+int svae_loss_reduce(const float* nll_row, const float* kl_row, const float* w_nll, const float* w_kl, float anneal,
+                     int R, float* out3, void* stream);
+
+/* ---- fused projection + log-softmax + NLL (bf16 MFMA path; logits are never materialised) -----------
+ * Replace Decoder.linear2 nb:710 + F.log_softmax nb:802 + likelihood nb:805-808 and their autograd.
+ * svae_proj_prep makes the bf16 operand copies (dst [n_pad][160], dstT [160][ldt]; ones_col >= 0 sets
+ * that column to 1.0); svae_proj_bias_consts the per-item constants.  See csrc/proj.hip. */
+int svae_proj_nsplit(void);
+int svae_proj_tile(void);
+int svae_proj_prep(const float* src, void* dst, void* dstT, int n, int n_pad, int ldt, int ones_col, void* stream);
+int svae_proj_bias_consts(const float* b3, float* ky_items, float* kx_items, int I, int I_pad, void* stream);
+int svae_proj_nll_fwd(const void* h2b, const void* w3b, const float* ky_items, const float* h2, const float* w3,
+                      const float* b3, const int* tgt, const float* w_nll, int R, int R_pad, int I, int K,
+                      float* part, float* nll_row, float* lse, float* kx_rows, float* ky_rows, void* stream);
+int svae_proj_nll_bwd(const void* h2b, const void* h2tb, int ldt_rows, const void* w3b, const void* w3tb,
+                      int ldt_items, const float* kx_rows, const float* ky_rows, const float* kx_items,
+                      const float* ky_items, const float* h2, const float* w3, const int* tgt, const float* w_nll,
+                      const int* occ_off, const int* occ_row, int R, int I, int I_pad, int K, float* slabs,
+                      float* dd1, float* gw3, float* gb3, void* stream);
+
+/* ---- Adam with L2 weight decay on one flat buffer ----------------------------------------------------
+ * Replaces optimizer.step() nb:1206 with torch.optim.Adam(weight_decay=5e-3) nb:1260-1263 (and the
+ * zero_grad pair nb:1197-1198: gradients are written, not accumulated).  step is 1-based. */
+int svae_adam_step(float* p, const float* g, float* m, float* v, long long n, int step, float lr, float b1, float b2,
+                   float eps, float wd, float gscale, void* stream);
+
+/* ---- scoring ------------------------------------------------------------------------------------------
+ * svae_masked_topk replaces the seen-item mask nb:621-624 and torch.sort(-scores)[:k] nb:632-636:
+ * score_i = s_i - |s_i * m_i| * 1e8, descending, ties by lower index.  seen / seen_off: CSR of each
+ * user's input items.  work: scratch [n_users][ld]. */
+int svae_masked_topk(const float* scores, int ld, const int* seen, const int* seen_off, int n_users, int I, int K,
+                     int* out_idx, float* out_val, float* work, void* stream);
+
+/* ---- helpers -------------------------------------------------------------------------------------------- */
+int svae_colsum(const float* a, float* out, float* partials, int R, int N, int ld, int nparts, void* stream);
+int svae_transpose(const float* in, float* out, int rows, int cols, void* stream);
+int svae_gather_rows(const float* in, const int* idx, float* out, int nrows, int ld_in, int ld_out, int n,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVAE_HIP_H */

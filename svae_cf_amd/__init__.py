@@ -4,3 +4,4 @@ filtering (reference: noveens/svae_cf, main_svae.ipynb).  HIP kernels behind a C
 from .batch import BatchPlan, build_plan, pack_rows, unpack_rows  # noqa: F401
 from .engine import PREC_BF16, PREC_FP32, SVAEEngine  # noqa: F401
 from .layout import ParamLayout  # noqa: F401
+from . import notebook_api  # noqa: F401,E402

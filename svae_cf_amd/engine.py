@@ -57,6 +57,8 @@ class SVAEEngine:
         self.fused = (prec == PREC_BF16)
         self.IPAD = (self.I + 63) // 64 * 64
         self.w3b = self.w3tb = None
+        self._last_fused = False
+        self._dtmp_extra = None
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.prof = None               # dict tag -> list of (start, end) torch.cuda.Event pairs
 
@@ -90,8 +92,7 @@ class SVAEEngine:
         shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dghn=HP, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
                       logits=self.IP, dz=L, dtmp=2 * L, dd1=DP, denc=DP, dhs=HP, dgi=G, demb=E,
                       kl_row=1, nll_row=1, lse=1)
-        if self.fused:
-            shapes["logits"] = 0
+        shapes["logits"] = 0                      # allocated on demand (_ensure_logits): fused mode never needs it
         self.ws = {k: torch.empty(cap * w, **f32) for k, w in shapes.items()}
         self.cap = cap
         if self.fused:
@@ -109,6 +110,10 @@ class SVAEEngine:
                 self.w3tb = torch.zeros(DP * self.IPAD, **bf)
                 self.ky_items = torch.zeros(self.IPAD, **f32)
                 self.kx_items = torch.zeros(self.IPAD, **f32)
+
+    def _ensure_logits(self):
+        if self.ws["logits"].numel() < self.cap * self.IP:
+            self.ws["logits"] = torch.empty(self.cap * self.IP, device=self.device, dtype=torch.float32)
 
     def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, al, bl, bias=None, act=0, aux=None, ldaux=0,
               nsplit=1, slab_stride=0, tag=None):
@@ -186,6 +191,7 @@ class SVAEEngine:
         self._gemm(w["z"], self.P("decoder.linear1.weight"), w["d1"], R, DP, L, L, L, DP, 0, 0,
                    bias=self.P("decoder.linear1.bias"), act=1)
         if self.fused and want_loss:
+            self._last_fused = True
             self._proj_prepare(R)
             Rp = (R + 63) // 64 * 64
             ev = self._tic("proj_fwd")
@@ -198,8 +204,10 @@ class SVAEEngine:
             _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
             return self.loss_out
-        if self.fused:
-            raise RuntimeError("dense logits are not kept in fused mode: use dense_logits()")
+        self._last_fused = False
+        if not want_loss:
+            return self.loss_out                  # callers of the dense surface use dense_logits()
+        self._ensure_logits()
         self._gemm(w["d1"], self.P("decoder.linear2.weight"), w["logits"], R, self.I, DP, DP, DP, self.IP, 0, 0,
                    bias=self.P("decoder.linear2.bias"), tag="proj_fwd")
         if want_loss:
@@ -256,7 +264,7 @@ class SVAEEngine:
         R, I, IP = plan.R, self.I, self.IP
         w, st = self.ws, _stream()
         lay = self.layout
-        if self.fused:
+        if self._last_fused:
             if plan.occ_off is None:
                 raise ValueError("fused mode needs build_plan(..., total_items=I)")
             Rp = (R + 63) // 64 * 64
@@ -284,6 +292,8 @@ class SVAEEngine:
         # latent
         _lib.call("svae_latent_bwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["dz"].data_ptr(),
                   plan.w_kl.data_ptr(), float(anneal), w["dtmp"].data_ptr(), R, st)
+        if self._dtmp_extra is not None:          # dense surface: dL/dmu, dL/dlog_sigma arriving from VAELoss
+            w["dtmp"][:R * 2 * L].add_(self._dtmp_extra.reshape(-1))
         self._wgrad(w["dtmp"], w["enc"], self.Gv("linear1.weight"), R, 2 * L, DP, 2 * L, DP)
         self._colsum(w["dtmp"], self.Gv("linear1.bias"), R, 2 * L, 2 * L)
         self._gemm(w["dtmp"], self.P("linear1.weight"), w["denc"], R, DP, 2 * L, 2 * L, DP, DP, 0, 1,
@@ -317,6 +327,50 @@ class SVAEEngine:
         _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
                   plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, 1.0, st)
         self._bucket(3)
+
+    # ------------------------------------------------------------------ dense (notebook) surface
+    def dense_loss(self, logits, mu, ls, tgt, anneal, batch_size=1.0):
+        """VAELoss.forward (nb:795-812) on dense logits [R, I]: returns (loss 0-dim tensor,
+        dL/dlogits [R, I], dL/d(mu|log_sigma) [R, 128]).  w_nll = 1/(batch_size*num_ones) with num_ones =
+        the first row's target count (nb:803), KL = mean over rows (nb:797)."""
+        R, I, IP, st = logits.shape[0], self.I, self.IP, _stream()
+        f32 = dict(device=self.device, dtype=torch.float32)
+        buf = torch.zeros(R * IP, **f32)
+        buf.view(R, IP)[:, :I].copy_(logits)
+        tgt = tgt.contiguous()
+        K = tgt.shape[1]
+        n0 = (tgt[0] >= 0).sum().to(torch.float32)
+        w_nll = (1.0 / (float(batch_size) * n0)).expand(R).contiguous()
+        w_kl = torch.full((R,), 1.0 / R, **f32)
+        tmp = torch.cat([mu, ls], dim=1).contiguous()
+        nll_row, kl_row, lse = torch.empty(R, **f32), torch.empty(R, **f32), torch.empty(R, **f32)
+        zeros = torch.zeros(R * L, **f32)
+        scratch = torch.empty(R * L, **f32)
+        dtmp = torch.empty(R, 2 * L, **f32)
+        out = torch.zeros(4, **f32)
+        _lib.call("svae_softmax_nll", buf.data_ptr(), tgt.data_ptr(), w_nll.data_ptr(), nll_row.data_ptr(),
+                  lse.data_ptr(), R, I, IP, K, 1, st)
+        _lib.call("svae_latent_fwd", tmp.data_ptr(), zeros.data_ptr(), scratch.data_ptr(), kl_row.data_ptr(), R, st)
+        _lib.call("svae_loss_reduce", nll_row.data_ptr(), kl_row.data_ptr(), w_nll.data_ptr(), w_kl.data_ptr(),
+                  float(anneal), R, out.data_ptr(), st)
+        _lib.call("svae_latent_bwd", tmp.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), w_kl.data_ptr(),
+                  float(anneal), dtmp.data_ptr(), R, st)
+        return out[0].clone(), buf.view(R, IP)[:, :I], dtmp
+
+    def backward_dense(self, plan, dlogits, dmu, dls):
+        """Backward of Model.forward given dense dL/d dec_out [R, I] and dL/dmu, dL/dlog_sigma [R, 64]
+        (what autograd hands to the notebook's Model at loss.backward(), nb:1205)."""
+        R = plan.R
+        self._ensure_logits()
+        buf = self.ws["logits"][:R * self.IP].view(R, self.IP)
+        buf.zero_()
+        buf[:, :self.I].copy_(dlogits)
+        self._plan, self._anneal, self._last_fused = plan, 0.0, False
+        self._dtmp_extra = torch.cat([dmu, dls], dim=1).contiguous()
+        try:
+            self.backward()
+        finally:
+            self._dtmp_extra = None
 
     # ------------------------------------------------------------------ optimizer
     def adam_step(self, gscale=1.0):

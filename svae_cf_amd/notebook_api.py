@@ -1,0 +1,437 @@
+"""The notebook's own surface -- Model / VAELoss / DataReader / train / evaluate / load_data -- on
+top of the HIP engine, so the reference's driver cell (nb:1235-1307, nb:1366-1382) runs unchanged
+except for its imports.  Same names, argument meaning and return values as main_svae.ipynb.
+
+Two ways to train:
+  * notebook style (batch_size 1, nb:80): ``train(reader)`` -> per user ``model(x)``,
+    ``criterion(...)``, ``loss.backward()``, ``optimizer.step()`` -- each of them runs HIP kernels
+    through torch.autograd.Function bridges (dense ``dec_out`` as in nb:768);
+  * batched: ``train_batched(...)`` packs B users per step (engine.train_step, fused kernels).
+``evaluate`` always batches users for scoring and reproduces the reference's metric arithmetic
+(nb:626-664) on the top-100 lists.
+"""
+import math
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .batch import build_plan
+from .engine import PREC_BF16, PREC_FP32, SVAEEngine, _stream
+from .layout import L
+
+
+def _xavier_normal(shape, gen):
+    std = math.sqrt(2.0 / (shape[0] + shape[1]))
+    return torch.randn(shape, generator=gen) * std
+
+
+def reference_init(total_items, hyper_params, seed=None):
+    """Parameter init with the reference's distributions (nb:690, 703-704, 730 xavier-normal Linear
+    weights; torch defaults elsewhere: Linear bias U(+-1/sqrt(fan_in)), Embedding N(0,1), GRU
+    U(+-1/sqrt(H)))."""
+    gen = torch.Generator().manual_seed(int(seed) if seed is not None else torch.seed() % (2 ** 31))
+    E, H = hyper_params["item_embed_size"], hyper_params["rnn_size"]
+    D, Lz = hyper_params["hidden_size"], hyper_params["latent_size"]
+    I = total_items
+
+    def u(shape, bound):
+        return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+    k = 1.0 / math.sqrt(H)
+    return {
+        "encoder.linear1.weight": _xavier_normal((D, H), gen), "encoder.linear1.bias": u((D,), 1 / math.sqrt(H)),
+        "decoder.linear1.weight": _xavier_normal((D, Lz), gen), "decoder.linear1.bias": u((D,), 1 / math.sqrt(Lz)),
+        "decoder.linear2.weight": _xavier_normal((I, D), gen), "decoder.linear2.bias": u((I,), 1 / math.sqrt(D)),
+        "item_embed.weight": torch.randn((I, E), generator=gen),
+        "gru.weight_ih_l0": u((3 * H, E), k), "gru.weight_hh_l0": u((3 * H, H), k),
+        "gru.bias_ih_l0": u((3 * H,), k), "gru.bias_hh_l0": u((3 * H,), k),
+        "linear1.weight": _xavier_normal((2 * Lz, D), gen), "linear1.bias": u((2 * Lz,), 1 / math.sqrt(D)),
+    }
+
+
+class SparseTargets:
+    """What DataReader yields instead of the dense one-hot y_s [1,T,I] (nb:500-513): the int32
+    table tgt [T, k] (-1 padded).  ``dense()`` gives the reference tensor when a caller wants it."""
+
+    def __init__(self, tgt, total_items):
+        self.tgt = tgt
+        self.total_items = total_items
+
+    def dense(self, device="cpu"):
+        T, K = self.tgt.shape
+        y = torch.zeros(1, T, self.total_items, device=device)
+        t = torch.as_tensor(self.tgt, device=device).long()
+        rows = torch.arange(T, device=device)[:, None].expand(T, K)
+        m = t >= 0
+        y[0, rows[m], t[m]] = 1.0
+        return y
+
+
+def _targets_from_dense(y):
+    """Dense one-hot [1,T,I] (any device) -> int32 [T,K] table, -1 padded."""
+    y2 = y[0]
+    K = int(y2.sum(-1).max().item())
+    vals, idx = torch.topk(y2, max(K, 1), dim=-1)
+    idx = idx.to(torch.int32)
+    idx[vals <= 0] = -1
+    return idx.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# autograd bridges
+# --------------------------------------------------------------------------------------------
+class _ForwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, model, plan, eps):
+        eng = model.engine
+        eng.forward(plan, 0.0, eps=eps, seed=model.noise_seed, step=model._calls, want_loss=False)
+        R = plan.R
+        dec = eng.dense_logits()[:, :eng.I].clone()
+        mu, ls = eng.mu_logsigma(R)
+        ctx.model, ctx.plan = model, plan
+        return dec.view(1, R, eng.I), mu.clone(), ls.clone()
+
+    @staticmethod
+    def backward(ctx, d_dec, d_mu, d_ls):
+        eng, plan = ctx.model.engine, ctx.plan
+        eng.backward_dense(plan, d_dec.reshape(plan.R, eng.I), d_mu, d_ls)
+        flat = ctx.model.flat
+        return eng.grads, None, None, None
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dec, mu, ls, model, tgt, anneal, batch_size):
+        eng = model.engine
+        R, I = dec.shape[1], dec.shape[2]
+        loss, dlogits, dtmp = eng.dense_loss(dec.reshape(R, I), mu, ls, tgt, float(anneal), batch_size)
+        ctx.save_for_backward(dlogits, dtmp)
+        ctx.shape = dec.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dlogits, dtmp = ctx.saved_tensors
+        return (g * dlogits).view(ctx.shape), g * dtmp[:, :L], g * dtmp[:, L:], None, None, None, None
+
+
+class Encoder:      # kept for name parity with nb:684-696; the layers live inside Model's engine
+    pass
+
+
+class Decoder:      # nb:698-711
+    pass
+
+
+class Model(torch.nn.Module):
+    """Drop-in for the notebook's Model (nb:713-768).  ``hyper_params`` needs total_items and, if
+    present, must carry the default sizes (256/200/150/64) the kernels are compiled for."""
+
+    def __init__(self, hyper_params, prec=PREC_FP32, device="cuda", seed=None):
+        super().__init__()
+        self.hyper_params = hyper_params
+        want = dict(item_embed_size=256, rnn_size=200, hidden_size=150, latent_size=64)
+        for k, v in want.items():
+            if hyper_params.get(k, v) != v:
+                raise ValueError("kernels are built for %s=%d (reference default), got %r" % (k, v, hyper_params[k]))
+        hp = dict(want)
+        hp.update({k: hyper_params[k] for k in want if k in hyper_params})
+        self.engine = SVAEEngine(hyper_params["total_items"], device=device, prec=prec,
+                                 weight_decay=hyper_params.get("weight_decay", 5e-3))
+        self.engine.fused = False if prec == PREC_FP32 else self.engine.fused
+        self.engine.load_state_dict(reference_init(hyper_params["total_items"], hp, seed))
+        self.flat = torch.nn.Parameter(self.engine.params, requires_grad=True)
+        self.noise_seed = 0 if seed is None else int(seed)
+        self._calls = 0
+        self.z_mean = self.z_log_sigma = None
+        self.eps_source = None      # optional callable (T, L) -> numpy noise (parity tests replay nb:744)
+
+    # reference-shaped state_dict (names / shapes of nb:718-729)
+    def state_dict(self, *a, **k):
+        return self.engine.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.engine.load_state_dict(sd)
+
+    def cuda(self, device=None):
+        return self
+
+    def forward(self, x):
+        """x: int64 [1, T].  Returns (dec_out [1,T,I], z_mean [T,64], z_log_sigma [T,64]) as nb:768."""
+        if x.dim() != 2 or x.shape[0] != 1:
+            raise ValueError("batch_size must be 1 on this surface (nb:80); use train_batched for more")
+        items = np.concatenate([x[0].detach().cpu().numpy().astype(np.int64), [0]])   # last item is not an input
+        plan = build_plan([items], 1, device=self.engine.device)
+        eps = None
+        if self.eps_source is not None:
+            eps = torch.as_tensor(np.asarray(self.eps_source(plan.R, L), dtype=np.float32)).to(self.engine.device)
+        self._calls += 1
+        self._last_x = x
+        dec, mu, ls = _ForwardFn.apply(self.flat, self, plan, eps)
+        self.z_mean, self.z_log_sigma = mu, ls
+        return dec, mu, ls
+
+
+class VAELoss(torch.nn.Module):
+    """Drop-in for nb:790-812.  ``y_true_s`` may be the reference's dense one-hot or SparseTargets."""
+
+    def __init__(self, hyper_params, model=None):
+        super().__init__()
+        self.hyper_params = hyper_params
+        self.model = model
+
+    def forward(self, decoder_output, mu_q, logvar_q, y_true_s, anneal):
+        model = self.model
+        if model is None:
+            raise RuntimeError("VAELoss needs the Model whose engine runs the kernels: VAELoss(hp, model)")
+        if isinstance(y_true_s, SparseTargets):
+            tgt = torch.as_tensor(y_true_s.tgt, dtype=torch.int32, device=decoder_output.device)
+        else:
+            tgt = _targets_from_dense(y_true_s).to(decoder_output.device)
+        return _LossFn.apply(decoder_output, mu_q, logvar_q, model, tgt, anneal,
+                             float(self.hyper_params.get("batch_size", 1)))
+
+
+class Adam:
+    """torch.optim.Adam(model.parameters(), weight_decay=wd) look-alike (nb:1260-1263) that runs the fused
+    HIP Adam over the engine's flat buffers."""
+
+    def __init__(self, model_or_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, model=None):
+        self.model = model if model is not None else model_or_params
+        if not isinstance(self.model, Model):
+            raise TypeError("pass the Model: Adam(model, weight_decay=...)")
+        e = self.model.engine
+        e.lr, e.betas, e.adam_eps, e.weight_decay = lr, betas, eps, weight_decay
+
+    def zero_grad(self):
+        pass        # gradients are written, never accumulated (nb:1197-1198 become no-ops)
+
+    def step(self):
+        self.model.engine.adam_step()
+
+
+# --------------------------------------------------------------------------------------------
+# data (nb:406-576)
+# --------------------------------------------------------------------------------------------
+class DataReader:
+    """Same constructor and semantics as nb:439-576; yields SparseTargets instead of dense y_s unless
+    hyper_params['dense_targets'] is true."""
+
+    def __init__(self, hyper_params, a, b, num_items, is_training):
+        self.hyper_params = hyper_params
+        self.batch_size = hyper_params["batch_size"]
+        self.num_items = num_items
+        self.is_training = is_training
+        ua = np.array([[int(v) for v in line.strip().split(",")[:2]] for line in a], dtype=np.int64).reshape(-1, 2)
+        self.min_user = int(ua[:, 0].min())
+        self.num_users = int(ua[:, 0].max()) - self.min_user + 1                   # nb:444-450
+        self.data = [[] for _ in range(self.num_users)]
+        for uid, sid in ua:
+            self.data[uid - self.min_user].append(int(sid))
+        self.data_te = None
+        if not is_training:
+            self.data_te = [[] for _ in range(self.num_users)]
+            for line in b:
+                uid, sid = [int(v) for v in line.strip().split(",")[:2]]
+                self.data_te[uid - self.min_user].append(sid)
+        self.num_b = int(min(len(self.data), hyper_params["number_users_to_keep"]) / self.batch_size)  # nb:482
+
+    def _k(self):
+        lt = self.hyper_params["loss_type"]
+        if lt == "predict_next":
+            return 1
+        if lt == "next_k":
+            return int(self.hyper_params["next_k"])
+        if lt == "postfix":
+            return 10 ** 9
+        raise ValueError("loss_type %r is not implemented by the reference reader either (nb:503-519)" % lt)
+
+    def _targets(self, items):
+        from .batch import build_plan as _bp
+        T = len(items) - 1
+        k = min(self._k(), T)
+        tgt = np.full((T, k), -1, dtype=np.int32)
+        arr = np.asarray(items, dtype=np.int64)
+        for j in range(k):
+            n = T - j
+            tgt[:n, j] = arr[1 + j:1 + j + n]
+        st = SparseTargets(tgt, self.num_items)
+        return st.dense() if self.hyper_params.get("dense_targets") else st
+
+    def user_order(self):
+        order = list(range(len(self.data)))
+        np.random.shuffle(order)                                                  # nb:493 (global numpy stream)
+        return order
+
+    def iter(self):
+        users_done = 0
+        for user in self.user_order():
+            if users_done > self.hyper_params["number_users_to_keep"]:
+                break
+            users_done += 1
+            items = self.data[user]
+            yield torch.as_tensor([items[:-1]], dtype=torch.int64), self._targets(items)
+
+    def eval_users(self):
+        """(fold_in items, held-out items) per user, as iter_eval splits them (nb:536-546)."""
+        out = []
+        for user in range(len(self.data)):
+            if len(out) >= self.hyper_params["number_users_to_keep"]:
+                break
+            if self.is_training:
+                split = float(self.hyper_params["history_split_test"][0])
+                n = int(split * len(self.data[user]))
+                out.append((self.data[user][:n], self.data[user][n:]))
+            else:
+                out.append((self.data[user], self.data_te[user]))
+        return out
+
+    def iter_eval(self):
+        for fold, held in self.eval_users():
+            yield (torch.as_tensor([fold[:-1]], dtype=torch.int64), self._targets(fold), [list(held)],
+                   [[1] * len(held)])
+
+
+def load_data(hyper_params):
+    """nb:406-437: reads pro_sg/{train,validation_tr,validation_te,test_tr,test_te}.csv + unique_sid.txt."""
+    base = hyper_params["data_base"]
+
+    def lines(name):
+        with open(base + name) as f:
+            return f.readlines()[1:]
+    with open(base + "unique_sid.txt") as f:
+        num_items = sum(1 for _ in f)
+    train_reader = DataReader(hyper_params, lines("train.csv"), None, num_items, True)
+    val_reader = DataReader(hyper_params, lines("validation_tr.csv"), lines("validation_te.csv"), num_items, False)
+    test_reader = DataReader(hyper_params, lines("test_tr.csv"), lines("test_te.csv"), num_items, False)
+    return train_reader, val_reader, test_reader, num_items
+
+
+# --------------------------------------------------------------------------------------------
+# train / evaluate (nb:1182-1233, nb:594-666)
+# --------------------------------------------------------------------------------------------
+def anneal_for_batch(b, total_anneal_steps=200000, cap=0.2):
+    """Anneal seen by the b-th step (1-based) of an epoch: the schedule's locals restart every epoch and
+    the value is updated AFTER use (nb:1188-1191, nb:1211-1215)."""
+    if b <= 2:
+        return 0.0
+    return min(cap, float(b - 2) / total_anneal_steps) if total_anneal_steps > 0 else cap
+
+
+def train(reader, model, optimizer, criterion, hyper_params, epoch=1, log=print):
+    """The notebook's train(reader) (nb:1182-1233) with its globals as arguments; same log line."""
+    model.train()
+    total_loss, start_time, batch = 0.0, time.time(), 0
+    batch_limit = int(reader.num_b)
+    interval = hyper_params["batch_log_interval"]
+    losses = []
+    for x, y_s in reader.iter():
+        batch += 1
+        model.zero_grad()
+        optimizer.zero_grad()
+        dec, mu, ls = model(x)
+        loss = criterion(dec, mu, ls, y_s, anneal_for_batch(batch))
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.detach())
+        if (batch % interval == 0 and batch > 0) or batch == batch_limit:
+            div = interval
+            if batch == batch_limit:
+                div = (batch_limit % interval) - 1                                # nb:1220 (off by one, kept)
+            if div <= 0:
+                div = 1
+            cur = float(torch.stack(losses).sum()) / div
+            log("| epoch {:3d} | {:5d}/{:5d} batches | ms/batch {:5.2f} | loss {:5.4f}".format(
+                epoch, batch, batch_limit, (time.time() - start_time) * 1000 / div, cur))
+            losses, start_time = [], time.time()
+    return batch
+
+
+def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, log=None, grad_sync=None,
+                  rank=0, world=1):
+    """One epoch with B users per step (length-bucketed, user-sharded over ranks).  The anneal schedule
+    counts optimizer steps exactly as the notebook counts batches."""
+    from .dist import shard_batches
+    from .synth import bucketed_batches
+    eng = model.engine
+    rng = np.random.default_rng(seed + 1000 * epoch)
+    lens = [len(u) for u in reader.data]
+    batches = shard_batches(bucketed_batches(lens, batch_size, rng), rank, world)
+    eng.grad_sync = grad_sync
+    k = reader._k()
+    for b, idx in enumerate(batches, start=1):
+        plan = build_plan([np.asarray(reader.data[i]) for i in idx], k, user_keys=idx, device=eng.device,
+                          total_items=eng.I)
+        eng.train_step(plan, anneal_for_batch(b), seed=seed + epoch)
+        if log is not None and b % max(1, hyper_params["batch_log_interval"] // batch_size) == 0:
+            log("| epoch {:3d} | {:5d}/{:5d} batches | loss {:5.4f}".format(epoch, b, len(batches), float(eng.loss_out[0])))
+    return len(batches)
+
+
+def _metrics_from_rankings(rec, held_lists, n_inputs, Ks=(10, 100)):
+    """Loop body nb:633-654 on precomputed descending rankings (rec[u] = top-max(Ks) item ids)."""
+    sums = {}
+    for k in Ks:
+        for nm in ("NDCG", "Rec", "Prec"):
+            sums["%s@%d" % (nm, k)] = 0.0
+    len_map = {}
+    for u, held in enumerate(held_lists):
+        for k in Ks:
+            rec_list = list(rec[u][:k])
+            best, now_at, dcg, hits = 0.0, 0.0, 0.0, 0.0
+            for movie in held:
+                now_at += 1.0
+                if now_at <= k:
+                    best += 1.0 / float(np.log2(now_at + 1))
+                if movie not in rec_list:
+                    continue
+                hits += 1.0
+                dcg += 1.0 / float(np.log2(float(rec_list.index(movie) + 2)))
+            sums["NDCG@%d" % k] += float(dcg) / float(best)
+            sums["Rec@%d" % k] += float(hits) / float(len(held))
+            sums["Prec@%d" % k] += float(hits) / float(k)
+            if k == 100:
+                len_map.setdefault(int(len(held)) + int(n_inputs[u]) + 1, []).append(float(dcg) / float(best))
+    return sums, len_map
+
+
+def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=64, eps_list=None, seed=0):
+    """nb:594-666.  Returns (metrics dict with the reference's 7 keys, len_to_ndcg_at_100_map).
+    Users are scored in batches; the loss is the mean of per-user reference losses at anneal 0.2
+    (nb:617), divided by ``batch`` exactly as the reference does (nb:658, one more than the users
+    scored when the train-set early break fired, nb:612-613)."""
+    eng = model.engine
+    pairs = reader.eval_users()
+    batch = len(pairs)
+    if is_train_set and len(pairs) > hyper_params["train_cp_users"]:
+        pairs = pairs[:hyper_params["train_cp_users"]]
+        batch = len(pairs) + 1
+    k = reader._k()
+    Ks = (10, 100)
+    loss_sum, sums, len_map = 0.0, None, {}
+    for s in range(0, len(pairs), batch_size):
+        chunk = pairs[s:s + batch_size]
+        plan = build_plan([np.asarray(f) for f, _ in chunk], k, user_keys=np.arange(s, s + len(chunk)),
+                          device=eng.device, total_items=eng.I)
+        eps = None
+        if eps_list is not None:
+            from .batch import pack_rows
+            eps = torch.from_numpy(pack_rows(plan, eps_list[s:s + len(chunk)], L)).to(eng.device)
+        out, idx, _, _ = eng.score(plan, max(Ks), eps=eps, seed=seed, step=s)
+        loss_sum += float(out[0]) * len(chunk)             # engine loss = mean over the chunk's users
+        idx = idx.cpu().numpy()
+        inv = np.empty(len(chunk), dtype=np.int64)
+        inv[plan.order] = np.arange(len(chunk))
+        rec = [idx[inv[u]] for u in range(len(chunk))]
+        cs, lm = _metrics_from_rankings(rec, [h for _, h in chunk], [len(f) - 1 for f, _ in chunk], Ks)
+        sums = cs if sums is None else {kk: sums[kk] + cs[kk] for kk in sums}
+        for kk, v in lm.items():
+            len_map.setdefault(kk, []).extend(v)
+    total_users = float(len(pairs))
+    metrics = {"loss": round(float(loss_sum) / float(batch), 4)}
+    for kk in Ks:
+        for nm in ("NDCG", "Rec", "Prec"):
+            key = "%s@%d" % (nm, kk)
+            metrics[key] = round((100.0 * sums[key]) / total_users, 4)
+    return metrics, len_map
