@@ -37,10 +37,11 @@ int svae_check_device(void); /* 0 if the current device is gfx950 */
  * GRU input GEMM inside nn.GRU nb:759, and their autograd GEMMs (nb:1205).
  * a_layout 0: A stored [M][K]; 1: A stored [K][M].  b_layout 0: B stored [N][K]; 1: B stored [K][N].
  * act 0 none, 1 tanh, 2 multiply by (1 - aux^2) (tanh backward).  nsplit > 1: split-K, split z writes
- * C + z*slab_stride (no epilogue); reduce with svae_reduce_slabs. */
-int svae_gemm(const float* A, const float* B, float* C, const float* bias, const float* aux, int M, int N, int K,
-              int lda, int ldb, int ldc, int ldaux, int a_layout, int b_layout, int act, int prec, int nsplit,
-              long long slab_stride, void* stream);
+ * C + z*slab_stride (no epilogue); reduce with svae_reduce_slabs.  colsum (optional, a_layout 1):
+ * colsum[m] = sum_k A(m,k) -- the bias gradient of a weight-gradient GEMM, folded into the same pass. */
+int svae_gemm(const float* A, const float* B, float* C, const float* bias, const float* aux, float* colsum, int M,
+              int N, int K, int lda, int ldb, int ldc, int ldaux, int a_layout, int b_layout, int act, int prec,
+              int nsplit, long long slab_stride, void* stream);
 int svae_reduce_slabs(const float* slabs, float* out, long long n, int nsplit, long long slab_stride, void* stream);
 
 /* ---- item embedding ----------------------------------------------------------------------------
@@ -57,11 +58,11 @@ int svae_embed_bwd(const float* demb, const int* perm, const int* seg_off, const
  * gi [R][672] = emb W_ih^T + b_ih (svae_gemm); whh [672][224], bhh [672].
  * Outputs hs [R][224], hprev [R][224] (h_{t-1}), gates4 [R][224][4] = (r, z, n, gh_n).
  * svae_gru_bwd replaces autograd through nn.GRU (nb:1205): whh_t = W_hh^T [224][672];
- * dhs [R][224] in; dgi [R][672] = d/d gi, dghn [R][224] = d/d gh_n out. */
+ * dhs [R][224] in; dgi [R][672] = d/d gi, dgh [R][672] = d/d gh out. */
 int svae_gru_fwd(const float* gi, const float* whh, const float* bhh, const int* row_off, const int* nact, int B,
                  int Tmax, float* hs, float* hprev, float* gates4, int prec, void* stream);
 int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t, const int* row_off,
-                 const int* nact, int B, int Tmax, float* dgi, float* dghn, int prec, void* stream);
+                 const int* nact, int B, int Tmax, float* dgi, float* dgh, int prec, void* stream);
 
 /* ---- latent: reparameterisation + KL ---------------------------------------------------------------
  * Replaces Model.sample_latent nb:734-750 and the KL term of VAELoss.forward nb:797.

@@ -24,6 +24,7 @@ constexpr int LDK16 = BK + 8;    // bf16, k-contiguous tile row stride (elements
 
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias; const float* aux;
+    float* colsum;      // optional (A layout 1 only): colsum[m] = sum_k A(m,k), one slab per split like C
     int M, N, K, lda, ldb, ldc, ldaux;
     int act;            // 0 none, 1 tanh, 2 multiply by (1 - aux^2)  (tanh backward)
     int ktiles_per_split;
@@ -142,12 +143,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int li = lane & 31, kk = lane >> 5;
+    // bias-gradient fold: the first column-tile's workgroups also sum their A tile over k
+    const bool do_cs = (AL == 1) && a.colsum != nullptr && blockIdx.x == 0 && tid < BM;
+    float cs = 0.f;
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int k0 = kt * BK;
         TA::stage(sA, a.A, a.lda, m0, k0, a.M, a.K, tid);
         TB::stage(sB, a.B, a.ldb, n0, k0, a.N, a.K, tid);
         __syncthreads();
+        if (AL == 1 && do_cs) {
+            if constexpr (PREC == 0) {
+#pragma unroll
+                for (int k = 0; k < BK; ++k) cs += reinterpret_cast<const float*>(sA)[k * LDM32 + tid];
+            } else {
+#pragma unroll
+                for (int k8 = 0; k8 < BK; k8 += 8) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(sA) + tid * LDK16 + k8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) cs += sv_bf2f((unsigned short)v[j]);
+                }
+            }
+        }
         if constexpr (PREC == 0) {
 #pragma unroll
             for (int kb = 0; kb < BK; kb += 8) {
@@ -185,6 +202,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
         __syncthreads();
     }
+
+    if (AL == 1 && do_cs && m0 + tid < a.M)
+        a.colsum[(size_t)blockIdx.z * a.slab_stride + m0 + tid] = cs;
 
     // epilogue: C layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* C = a.C + (size_t)blockIdx.z * a.slab_stride;
@@ -234,9 +254,9 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 
 }  // namespace
 
-extern "C" int svae_gemm(const float* A, const float* B, float* C, const float* bias, const float* aux, int M,
-                         int N, int K, int lda, int ldb, int ldc, int ldaux, int a_layout, int b_layout, int act,
-                         int prec, int nsplit, long long slab_stride, void* stream) {
+extern "C" int svae_gemm(const float* A, const float* B, float* C, const float* bias, const float* aux,
+                         float* colsum, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int a_layout,
+                         int b_layout, int act, int prec, int nsplit, long long slab_stride, void* stream) {
     SV_CHECK_ARG(A && B && C, "svae_gemm: null pointer");
     SV_CHECK_ARG(M > 0 && N > 0 && K > 0, "svae_gemm: bad shape %d %d %d", M, N, K);
     SV_CHECK_ARG((lda % 4) == 0 && (ldb % 4) == 0, "svae_gemm: lda/ldb must be multiples of 4");
@@ -247,8 +267,9 @@ extern "C" int svae_gemm(const float* A, const float* B, float* C, const float* 
     SV_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || slab_stride >= (long long)M * ldc), "svae_gemm: bad split");
     SV_CHECK_ARG(nsplit == 1 || (bias == nullptr && act == 0), "svae_gemm: split-K takes no epilogue");
     SV_CHECK_ARG(act != 2 || aux, "svae_gemm: act 2 needs aux");
+    SV_CHECK_ARG(colsum == nullptr || a_layout == 1, "svae_gemm: colsum needs an m-contiguous A");
     SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gemm: prec must be 0 (fp32) or 1 (bf16)");
-    GemmArgs a{A, B, C, bias, aux, M, N, K, lda, ldb, ldc, ldaux, act, 0, slab_stride};
+    GemmArgs a{A, B, C, bias, aux, colsum, M, N, K, lda, ldb, ldc, ldaux, act, 0, slab_stride};
     const int kt = (K + BK - 1) / BK;
     a.ktiles_per_split = (kt + nsplit - 1) / nsplit;
     hipStream_t st = (hipStream_t)stream;

@@ -11,7 +11,7 @@
 //
 // The input-side gates gi = emb W_ih^T + b_ih for all rows are computed beforehand by one big GEMM.
 // This file: the recurrent part, gh = h_{t-1} W_hh^T + b_hh, the fused gate math, and the reverse-time
-// BPTT that produces dgi / dgh_n for the weight-gradient GEMMs.
+// BPTT that produces dgi / dgh for the weight-gradient GEMMs.
 //
 //   fp32 mode: v_mfma_f32_16x16x4_f32, W_hh streamed from L2 every step (480 KB fp32 does not fit a CU)
 //   bf16 mode: v_mfma_f32_16x16x32_bf16, W_hh fragments resident in VGPRs/AGPRs for the whole sequence
@@ -42,7 +42,7 @@ struct GruArgs {
     float* gates4;        // [R][224][4]  r, z, n, gh_n  (fwd out / bwd in)
     const float* dhs;     // [R][224]  (bwd in) dL/dh_t from the encoder side
     float* dgi;           // [R][672]  (bwd out) d/d(gi) = (dr_pre, dz_pre, dn_pre)
-    float* dghn;          // [R][224]  (bwd out) d/d(gh_n) = dn_pre * r      (dgh_r = dgi_r, dgh_z = dgi_z)
+    float* dgh;           // [R][672]  (bwd out) d/d(gh) = (dr_pre, dz_pre, dn_pre * r)
     int B, Tmax;
 };
 
@@ -76,7 +76,10 @@ __device__ __forceinline__ float gate_bwd(const GruArgs& a, size_t row, int j, f
     o1[j] = drp;
     o1[SV_HP + j] = dzp;
     o1[2 * SV_HP + j] = dnp;
-    a.dghn[row * SV_HP + j] = dnr;
+    float* o2 = a.dgh + row * SV_G;
+    o2[j] = drp;
+    o2[SV_HP + j] = dzp;
+    o2[2 * SV_HP + j] = dnr;
     return d * zg;
 }
 
@@ -522,7 +525,7 @@ static int check_gru(const GruArgs& a, bool bwd) {
     SV_CHECK_ARG(a.whh && a.row_off && a.nact && a.hprev && a.gates4, "svae_gru: null pointer");
     SV_CHECK_ARG(a.B > 0 && a.Tmax > 0, "svae_gru: empty batch (B=%d Tmax=%d)", a.B, a.Tmax);
     if (!bwd) SV_CHECK_ARG(a.gi && a.bhh && a.hs, "svae_gru_fwd: null pointer");
-    if (bwd) SV_CHECK_ARG(a.dhs && a.dgi && a.dghn, "svae_gru_bwd: null pointer");
+    if (bwd) SV_CHECK_ARG(a.dhs && a.dgi && a.dgh, "svae_gru_bwd: null pointer");
     return 0;
 }
 
@@ -549,10 +552,10 @@ extern "C" int svae_gru_fwd(const float* gi, const float* whh, const float* bhh,
 // Reference interface replaced: autograd through nn.GRU at loss.backward() (nb:1205).
 // whh_t is W_hh transposed, [224][672].
 extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
-                            const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dghn,
+                            const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dgh,
                             int prec, void* stream) {
     GruArgs a{nullptr, whh_t, nullptr, row_off, nact, nullptr, const_cast<float*>(hprev),
-              const_cast<float*>(gates4), dhs, dgi, dghn, B, Tmax};
+              const_cast<float*>(gates4), dhs, dgi, dgh, B, Tmax};
     if (int e = check_gru(a, true)) return e;
     SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gru_bwd: bad prec %d", prec);
     dim3 grid((B + MB - 1) / MB);

@@ -365,42 +365,72 @@ __global__ void proj_dh_finish_kernel(const float* __restrict__ slabs, const flo
     reinterpret_cast<float4*>(dd1 + (size_t)row * KP)[lane] = o;
 }
 
-// dL/dW3, dL/db3 finish: one wave per item: sum the slabs, subtract sum over the item's target
-// occurrences (pairs sorted by item on the host: occ_row lists the data rows) of w_r h2[r];
-// column 150 of the slab sum is the bias gradient (ones column), its target part is -sum w_r.
-__global__ void proj_dw_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ h2,
-                                      const float* __restrict__ w_nll, const int* __restrict__ occ_off,
-                                      const int* __restrict__ occ_row, float* __restrict__ gw3,
-                                      float* __restrict__ gb3, int I, int I_pad) {
-    const int lane = threadIdx.x & 63;
-    const int it = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (it >= I_pad || lane >= KP / 4) return;
+// dL/dW3, dL/db3 finish: one workgroup per item.  Wave 0 sums the slabs; the item's target occurrences
+// (pairs sorted by item on the host: occ_row lists the data rows) are split over the 4 waves, 4 in flight
+// per wave, and their partial sums are added in a fixed order (bitwise reproducible).  Column 150 of the
+// slab sum is the bias gradient (ones column), its target part is -sum w_r.
+__global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __restrict__ slabs,
+                                                             const float* __restrict__ h2,
+                                                             const float* __restrict__ w_nll,
+                                                             const int* __restrict__ occ_off,
+                                                             const int* __restrict__ occ_row, float* __restrict__ gw3,
+                                                             float* __restrict__ gb3, int I, int I_pad) {
+    __shared__ float4 red[4][KP / 4];
+    __shared__ float wred[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int it = blockIdx.x;
+    const int ln = lane < KP / 4 ? lane : 0;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wsum = 0.f;
     if (it < I) {
-        for (int z = 0; z < NSPLIT; ++z) {
-            const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * I + it) * KP)[lane];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if (wave == 0) {
+            for (int z = 0; z < NSPLIT; ++z) {
+                const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * I + it) * KP)[ln];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
         }
-        float wsum = 0.f;
         const int b = occ_off[it], e = occ_off[it + 1];
-        for (int o = b; o < e; ++o) {
-            const int r = occ_row[o];
-            const float w = w_nll[r];
-            const float4 v = reinterpret_cast<const float4*>(h2 + (size_t)r * KP)[lane];
-            s.x -= w * v.x; s.y -= w * v.y; s.z -= w * v.z; s.w -= w * v.w;
-            wsum += w;
+        for (int o = b + wave; o < e; o += 16) {
+            int r[4];
+            float w[4];
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (o + 4 * j < e) ? occ_row[o + 4 * j] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = r[j] < 0 ? 0 : r[j];
+                w[j] = r[j] < 0 ? 0.f : w_nll[rr];
+                v[j] = reinterpret_cast<const float4*>(h2 + (size_t)rr * KP)[ln];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s.x -= w[j] * v[j].x; s.y -= w[j] * v[j].y; s.z -= w[j] * v[j].z; s.w -= w[j] * v[j].w;
+                wsum += w[j];
+            }
         }
+    }
+    if (lane < KP / 4) red[wave][lane] = s;
+    if (lane == 0) wred[wave] = wsum;
+    __syncthreads();
+    if (wave != 0 || lane >= KP / 4) return;
+    float4 t = red[0][lane];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        const float4 u = red[q][lane];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    if (it < I) {
         if (lane == SV_D / 4) {          // lane 37 holds columns 148..151: column 150 = bias gradient
-            gb3[it] = s.z - wsum;
-            s.z = 0.f;
+            gb3[it] = t.z - (wred[0] + wred[1] + wred[2] + wred[3]);
+            t.z = 0.f;
         }
         const int c0 = 4 * lane;
-        if (c0 + 0 >= SV_D) s.x = 0.f;
-        if (c0 + 1 >= SV_D) s.y = 0.f;
-        if (c0 + 2 >= SV_D) s.z = 0.f;
-        if (c0 + 3 >= SV_D) s.w = 0.f;
+        if (c0 + 0 >= SV_D) t.x = 0.f;
+        if (c0 + 1 >= SV_D) t.y = 0.f;
+        if (c0 + 2 >= SV_D) t.z = 0.f;
+        if (c0 + 3 >= SV_D) t.w = 0.f;
     }
-    reinterpret_cast<float4*>(gw3 + (size_t)it * KP)[lane] = s;
+    reinterpret_cast<float4*>(gw3 + (size_t)it * KP)[lane] = t;
 }
 
 template <int MODE>
@@ -483,7 +513,7 @@ extern "C" int svae_proj_nll_bwd(const void* h2b, const void* h2tb, int ldt_rows
         const int ntiles = (R + BY - 1) / BY;
         a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
         if (int e = launch_proj<MODE_DW>(a, st)) return e;
-        hipLaunchKernelGGL(proj_dw_finish_kernel, dim3((I_pad + 3) / 4), dim3(256), 0, st, slabs, h2, w_nll, occ_off,
+        hipLaunchKernelGGL(proj_dw_finish_kernel, dim3(I_pad), dim3(256), 0, st, slabs, h2, w_nll, occ_off,
                            occ_row, gw3, gb3, I, I_pad);
         SV_LAUNCH_CHECK();
     }

@@ -49,7 +49,7 @@ class SVAEEngine:
         self.cap = 0
         self.ws = {}
         self.nsplit = 32
-        self.slabs = torch.zeros(self.nsplit * G * E, **f32)        # largest split-K output: dW_ih
+        self.slabs = torch.zeros(self.nsplit * (G * E + G), **f32)        # largest split-K output: dW_ih
         self.colparts = torch.zeros(64 * max(self.IP, G), **f32)
         self._plan = None
         self._anneal = 0.0
@@ -89,7 +89,7 @@ class SVAEEngine:
             return
         cap = int(R * 1.25) + 64
         f32 = dict(device=self.device, dtype=torch.float32)
-        shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dghn=HP, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
+        shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dgh=G, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
                       logits=self.IP, dz=L, dtmp=2 * L, dd1=DP, denc=DP, dhs=HP, dgi=G, demb=E,
                       kl_row=1, nll_row=1, lse=1)
         shapes["logits"] = 0                      # allocated on demand (_ensure_logits): fused mode never needs it
@@ -116,10 +116,10 @@ class SVAEEngine:
             self.ws["logits"] = torch.empty(self.cap * self.IP, device=self.device, dtype=torch.float32)
 
     def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, al, bl, bias=None, act=0, aux=None, ldaux=0,
-              nsplit=1, slab_stride=0, tag=None):
+              nsplit=1, slab_stride=0, tag=None, colsum=None):
         ev = self._tic(tag)
         _lib.call("svae_gemm", A.data_ptr(), B.data_ptr(), C.data_ptr(), _lib.ptr(bias), _lib.ptr(aux),
-                  M, N, K, lda, ldb, ldc, ldaux, al, bl, act, self.prec, nsplit, slab_stride, _stream())
+                  _lib.ptr(colsum), M, N, K, lda, ldb, ldc, ldaux, al, bl, act, self.prec, nsplit, slab_stride, _stream())
         self._toc(tag, ev)
 
     def _tic(self, tag):
@@ -140,14 +140,19 @@ class SVAEEngine:
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(i)
 
-    def _wgrad(self, dY, X, out, R, N, K, ldy, ldx):
-        """out[N][K] = dY[R][N]^T X[R][K] with split-K over rows (deterministic slab reduce)."""
+    def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx):
+        """Weight + bias gradient of y = x W^T + b in one pass: gW[N][K] = dY[R][N]^T X[R][K] and
+        gb[N] = column sums of dY (folded into the GEMM).  Split-K over rows writes one slab per split
+        (weights then bias), summed in a fixed order: deterministic, no atomics.  The bias gradient sits
+        right behind the weight gradient in the flat buffer (layout.py keeps them adjacent)."""
+        out = self.grads[self.layout.offset(wname):]
         ns = max(1, min(self.nsplit, (R + 255) // 256))
         if ns == 1:
-            self._gemm(dY, X, out, N, K, R, ldy, ldx, K, 1, 1)
+            self._gemm(dY, X, out, N, K, R, ldy, ldx, K, 1, 1, colsum=out[N * K:])
         else:
-            stride = N * K
-            self._gemm(dY, X, self.slabs, N, K, R, ldy, ldx, K, 1, 1, nsplit=ns, slab_stride=stride)
+            stride = N * K + N
+            self._gemm(dY, X, self.slabs, N, K, R, ldy, ldx, K, 1, 1, nsplit=ns, slab_stride=stride,
+                       colsum=self.slabs[N * K:])
             _lib.call("svae_reduce_slabs", self.slabs.data_ptr(), out.data_ptr(), stride, ns, stride, _stream())
 
     def _colsum(self, A, out, R, N, ld):
@@ -286,21 +291,18 @@ class SVAEEngine:
             self._gemm(dl, self.P("decoder.linear2.weight"), w["dd1"], R, DP, IP, IP, DP, DP, 0, 1,
                        act=2, aux=w["d1"], ldaux=DP, tag="proj_dx")
         # decoder.linear1
-        self._wgrad(w["dd1"], w["z"], self.Gv("decoder.linear1.weight"), R, DP, L, DP, L)
-        self._colsum(w["dd1"], self.Gv("decoder.linear1.bias"), R, DP, DP)
+        self._wgrad(w["dd1"], w["z"], "decoder.linear1.weight", R, DP, L, DP, L)
         self._gemm(w["dd1"], self.P("decoder.linear1.weight"), w["dz"], R, L, DP, DP, L, L, 0, 1)
         # latent
         _lib.call("svae_latent_bwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["dz"].data_ptr(),
                   plan.w_kl.data_ptr(), float(anneal), w["dtmp"].data_ptr(), R, st)
         if self._dtmp_extra is not None:          # dense surface: dL/dmu, dL/dlog_sigma arriving from VAELoss
             w["dtmp"][:R * 2 * L].add_(self._dtmp_extra.reshape(-1))
-        self._wgrad(w["dtmp"], w["enc"], self.Gv("linear1.weight"), R, 2 * L, DP, 2 * L, DP)
-        self._colsum(w["dtmp"], self.Gv("linear1.bias"), R, 2 * L, 2 * L)
+        self._wgrad(w["dtmp"], w["enc"], "linear1.weight", R, 2 * L, DP, 2 * L, DP)
         self._gemm(w["dtmp"], self.P("linear1.weight"), w["denc"], R, DP, 2 * L, 2 * L, DP, DP, 0, 1,
                    act=2, aux=w["enc"], ldaux=DP)
         # encoder.linear1
-        self._wgrad(w["denc"], w["hs"], self.Gv("encoder.linear1.weight"), R, DP, HP, DP, HP)
-        self._colsum(w["denc"], self.Gv("encoder.linear1.bias"), R, DP, DP)
+        self._wgrad(w["denc"], w["hs"], "encoder.linear1.weight", R, DP, HP, DP, HP)
         self._gemm(w["denc"], self.P("encoder.linear1.weight"), w["dhs"], R, HP, DP, DP, HP, HP, 0, 1)
         self._bucket(1)
         # GRU (BPTT)
@@ -308,17 +310,10 @@ class SVAEEngine:
         ev = self._tic("gru_bwd")
         _lib.call("svae_gru_bwd", w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
                   self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
-                  w["dgi"].data_ptr(), w["dghn"].data_ptr(), self.gru_prec, st)
+                  w["dgi"].data_ptr(), w["dgh"].data_ptr(), self.gru_prec, st)
         self._toc("gru_bwd", ev)
-        # dgh = (dgi_r, dgi_z, dghn): W_hh rows of gates r,z take dgi's first 448 columns, gate n takes dghn
-        gwhh = self.Gv("gru.weight_hh_l0").view(-1)
-        gbhh = self.Gv("gru.bias_hh_l0").view(-1)
-        self._wgrad(w["dgi"], w["hprev"], gwhh, R, 2 * HP, HP, G, HP)
-        self._wgrad(w["dghn"], w["hprev"], gwhh[2 * HP * HP:], R, HP, HP, HP, HP)
-        self._colsum(w["dgi"], gbhh, R, 2 * HP, G)
-        self._colsum(w["dghn"], gbhh[2 * HP:], R, HP, HP)
-        self._wgrad(w["dgi"], w["emb"], self.Gv("gru.weight_ih_l0"), R, G, E, G, E)
-        self._colsum(w["dgi"], self.Gv("gru.bias_ih_l0"), R, G, G)
+        self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
+        self._wgrad(w["dgi"], w["emb"], "gru.weight_ih_l0", R, G, E, G, E)
         self._bucket(2)
         self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
         # embedding: dense gradient, zero + deterministic segmented scatter-add

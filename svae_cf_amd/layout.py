@@ -50,6 +50,10 @@ class ParamLayout:
         off = 0
         for name, g, r, c, pr, pc in spec:
             size = g * pr * pc
+            if name.endswith(".bias") or name.startswith("gru.bias"):
+                # a bias sits right behind its weight: the weight-gradient GEMM writes [gW | gb] in one slab
+                prev = list(self.entries.values())[-1]
+                assert off == prev.offset + prev.size, name
             self.entries[name] = Entry(name, off, g, r, c, pr, pc, size)
             off = _round_up(off + size, 64)     # every tensor starts 256-byte aligned
         self.total = off
