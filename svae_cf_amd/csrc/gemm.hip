@@ -31,23 +31,51 @@ struct GemmArgs {
     long long slab_stride;
 };
 
+// Staging is split (register staging, issue-early / write-late): load() puts a thread's 4 float4 of the
+// NEXT k-tile in flight before the MFMAs of the current one, store() converts and writes them to LDS after.
+// The four staged float4 are separate scalars (an array member ended up in scratch) and every load is
+// unconditional (address clamped, value selected), so the 8 loads of a tile issue back to back.
+#define SV_R4 float4 &v0, float4 &v1, float4 &v2, float4 &v3
+#define SV_CR4 const float4 &v0, const float4 &v1, const float4 &v2, const float4 &v3
+
+__device__ __forceinline__ float4 ld4(const float* g, size_t off, bool ok) {
+    const float4 t = *reinterpret_cast<const float4*>(g + (ok ? off : 0));
+    return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    const h2 h = __builtin_convertvector(v, h2);
+    return *reinterpret_cast<const unsigned*>(&h);
+}
+
 template <int PREC, int L>
 struct Tile;  // LDS image of one operand tile (rows = m or n index, BK k's)
 
+// k-contiguous source: thread (row = idx>>3, c4 = idx&7), idx = tid + 256 i: 8 lanes read one row's 128 B
+struct TileK {
+    static __device__ __forceinline__ void load(SV_R4, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
+        const int row = tid >> 3, gk = k0 + 4 * (tid & 7);
+        const bool kok = gk < K;
+        v0 = ld4(g, (size_t)(r0 + row) * ld + gk, kok && (r0 + row) < R);
+        v1 = ld4(g, (size_t)(r0 + row + 32) * ld + gk, kok && (r0 + row + 32) < R);
+        v2 = ld4(g, (size_t)(r0 + row + 64) * ld + gk, kok && (r0 + row + 64) < R);
+        v3 = ld4(g, (size_t)(r0 + row + 96) * ld + gk, kok && (r0 + row + 96) < R);
+    }
+};
+
 // ---- fp32 tiles ----
 template <>
-struct Tile<0, 0> {  // k-contiguous source: image [128][36] floats
+struct Tile<0, 0> : TileK {  // image [128][36] floats
     static constexpr int BYTES = 128 * LDK32 * 4;
-    static __device__ __forceinline__ void stage(float* s, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int idx = tid + i * 256;
-            int row = idx >> 3, c4 = idx & 7;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int gr = r0 + row, gk = k0 + 4 * c4;
-            if (gr < R && gk < K) v = *reinterpret_cast<const float4*>(g + (size_t)gr * ld + gk);
-            *reinterpret_cast<float4*>(s + row * LDK32 + 4 * c4) = v;
-        }
+    static __device__ __forceinline__ void store(SV_CR4, float* s, int tid) {
+        float* d = s + (tid >> 3) * LDK32 + 4 * (tid & 7);
+        *reinterpret_cast<float4*>(d) = v0;
+        *reinterpret_cast<float4*>(d + 32 * LDK32) = v1;
+        *reinterpret_cast<float4*>(d + 64 * LDK32) = v2;
+        *reinterpret_cast<float4*>(d + 96 * LDK32) = v3;
     }
     // fragment for MFMA steps kb..: lane (i = l&31, kk = l>>5) -> 4 consecutive k's
     static __device__ __forceinline__ float4 frag(const float* s, int row, int kb, int kk) {
@@ -55,18 +83,22 @@ struct Tile<0, 0> {  // k-contiguous source: image [128][36] floats
     }
 };
 template <>
-struct Tile<0, 1> {  // m-contiguous source: image [32][132] floats
+struct Tile<0, 1> {  // m-contiguous source: image [32][132] floats; thread (k = tid>>5 + 8 i, c4 = tid&31)
     static constexpr int BYTES = BK * LDM32 * 4;
-    static __device__ __forceinline__ void stage(float* s, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int idx = tid + i * 256;
-            int k = idx >> 5, c4 = idx & 31;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int gk = k0 + k, gr = r0 + 4 * c4;
-            if (gk < K && gr < R) v = *reinterpret_cast<const float4*>(g + (size_t)gk * ld + gr);
-            *reinterpret_cast<float4*>(s + k * LDM32 + 4 * c4) = v;
-        }
+    static __device__ __forceinline__ void load(SV_R4, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
+        const int k = k0 + (tid >> 5), gr = r0 + 4 * (tid & 31);
+        const bool rok = gr < R;
+        v0 = ld4(g, (size_t)k * ld + gr, rok && k < K);
+        v1 = ld4(g, (size_t)(k + 8) * ld + gr, rok && (k + 8) < K);
+        v2 = ld4(g, (size_t)(k + 16) * ld + gr, rok && (k + 16) < K);
+        v3 = ld4(g, (size_t)(k + 24) * ld + gr, rok && (k + 24) < K);
+    }
+    static __device__ __forceinline__ void store(SV_CR4, float* s, int tid) {
+        float* d = s + (tid >> 5) * LDM32 + 4 * (tid & 31);
+        *reinterpret_cast<float4*>(d) = v0;
+        *reinterpret_cast<float4*>(d + 8 * LDM32) = v1;
+        *reinterpret_cast<float4*>(d + 16 * LDM32) = v2;
+        *reinterpret_cast<float4*>(d + 24 * LDM32) = v3;
     }
     static __device__ __forceinline__ float4 frag(const float* s, int row, int kb, int kk) {
         const float* p = s + (kb + 4 * kk) * LDM32 + row;
@@ -76,44 +108,36 @@ struct Tile<0, 1> {  // m-contiguous source: image [32][132] floats
 
 // ---- bf16 tiles: image always [128][40] bf16, k contiguous ----
 template <>
-struct Tile<1, 0> {
+struct Tile<1, 0> : TileK {
     static constexpr int BYTES = 128 * LDK16 * 2;
-    static __device__ __forceinline__ void stage(unsigned short* s, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int idx = tid + i * 256;
-            int row = idx >> 3, c4 = idx & 7;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int gr = r0 + row, gk = k0 + 4 * c4;
-            if (gr < R && gk < K) v = *reinterpret_cast<const float4*>(g + (size_t)gr * ld + gk);
-            uint2 pk;
-            pk.x = (unsigned)sv_f2bf(v.x) | ((unsigned)sv_f2bf(v.y) << 16);
-            pk.y = (unsigned)sv_f2bf(v.z) | ((unsigned)sv_f2bf(v.w) << 16);
-            *reinterpret_cast<uint2*>(s + row * LDK16 + 4 * c4) = pk;
-        }
+    static __device__ __forceinline__ void store(SV_CR4, unsigned short* s, int tid) {
+        unsigned short* d = s + (tid >> 3) * LDK16 + 4 * (tid & 7);
+        *reinterpret_cast<uint2*>(d) = make_uint2(pk2(v0.x, v0.y), pk2(v0.z, v0.w));
+        *reinterpret_cast<uint2*>(d + 32 * LDK16) = make_uint2(pk2(v1.x, v1.y), pk2(v1.z, v1.w));
+        *reinterpret_cast<uint2*>(d + 64 * LDK16) = make_uint2(pk2(v2.x, v2.y), pk2(v2.z, v2.w));
+        *reinterpret_cast<uint2*>(d + 96 * LDK16) = make_uint2(pk2(v3.x, v3.y), pk2(v3.z, v3.w));
     }
 };
+// m-contiguous source, transposed while staging: a thread owns a 4k x 4m block, kg = tid&7, mg = tid>>3.
+// A wave-load touches 8 k-rows x 128 B; the 8-byte LDS writes of a 16-lane group fall in two rows 80 dwords
+// apart: conflict-free (an mg-fastest map was 16-way conflicted: SQ_LDS_BANK_CONFLICT = 77 % of LDS cycles).
 template <>
-struct Tile<1, 1> {  // m-contiguous source, transposed while staging (4x4 register transpose)
+struct Tile<1, 1> {
     static constexpr int BYTES = 128 * LDK16 * 2;
-    static __device__ __forceinline__ void stage(unsigned short* s, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
-        // 32 k x 128 m tile = 8 k-groups(4) x 32 m-groups(4) = 256 blocks of 4x4: one per thread
-        int kg = tid >> 5, mg = tid & 31;
-        float4 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int gk = k0 + 4 * kg + j, gr = r0 + 4 * mg;
-            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gk < K && gr < R) v[j] = *reinterpret_cast<const float4*>(g + (size_t)gk * ld + gr);
-        }
-        const float* f = reinterpret_cast<const float*>(v);
-#pragma unroll
-        for (int mm = 0; mm < 4; ++mm) {
-            uint2 pk;
-            pk.x = (unsigned)sv_f2bf(f[0 * 4 + mm]) | ((unsigned)sv_f2bf(f[1 * 4 + mm]) << 16);
-            pk.y = (unsigned)sv_f2bf(f[2 * 4 + mm]) | ((unsigned)sv_f2bf(f[3 * 4 + mm]) << 16);
-            *reinterpret_cast<uint2*>(s + (4 * mg + mm) * LDK16 + 4 * kg) = pk;
-        }
+    static __device__ __forceinline__ void load(SV_R4, const float* g, int ld, int r0, int k0, int R, int K, int tid) {
+        const int k = k0 + 4 * (tid & 7), gr = r0 + 4 * (tid >> 3);
+        const bool rok = gr < R;
+        v0 = ld4(g, (size_t)k * ld + gr, rok && k < K);
+        v1 = ld4(g, (size_t)(k + 1) * ld + gr, rok && (k + 1) < K);
+        v2 = ld4(g, (size_t)(k + 2) * ld + gr, rok && (k + 2) < K);
+        v3 = ld4(g, (size_t)(k + 3) * ld + gr, rok && (k + 3) < K);
+    }
+    static __device__ __forceinline__ void store(SV_CR4, unsigned short* s, int tid) {
+        unsigned short* d = s + (4 * (tid >> 3)) * LDK16 + 4 * (tid & 7);
+        *reinterpret_cast<uint2*>(d) = make_uint2(pk2(v0.x, v1.x), pk2(v2.x, v3.x));
+        *reinterpret_cast<uint2*>(d + LDK16) = make_uint2(pk2(v0.y, v1.y), pk2(v2.y, v3.y));
+        *reinterpret_cast<uint2*>(d + 2 * LDK16) = make_uint2(pk2(v0.z, v1.z), pk2(v2.z, v3.z));
+        *reinterpret_cast<uint2*>(d + 3 * LDK16) = make_uint2(pk2(v0.w, v1.w), pk2(v2.w, v3.w));
     }
 };
 
@@ -147,11 +171,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     const bool do_cs = (AL == 1) && a.colsum != nullptr && blockIdx.x == 0 && tid < BM;
     float cs = 0.f;
 
+    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+    if (kt_begin < kt_end) {
+        TA::load(a0, a1, a2, a3, a.A, a.lda, m0, kt_begin * BK, a.M, a.K, tid);
+        TB::load(b0, b1, b2, b3, a.B, a.ldb, n0, kt_begin * BK, a.N, a.K, tid);
+        TA::store(a0, a1, a2, a3, sA, tid);
+        TB::store(b0, b1, b2, b3, sB, tid);
+    }
+    __syncthreads();
+
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int k0 = kt * BK;
-        TA::stage(sA, a.A, a.lda, m0, k0, a.M, a.K, tid);
-        TB::stage(sB, a.B, a.ldb, n0, k0, a.N, a.K, tid);
-        __syncthreads();
+        const bool more = (kt + 1) < kt_end;
+        if (more) {   // next tile's global loads fly under this tile's MFMAs
+            TA::load(a0, a1, a2, a3, a.A, a.lda, m0, (kt + 1) * BK, a.M, a.K, tid);
+            TB::load(b0, b1, b2, b3, a.B, a.ldb, n0, (kt + 1) * BK, a.N, a.K, tid);
+        }
         if (AL == 1 && do_cs) {
             if constexpr (PREC == 0) {
 #pragma unroll
@@ -200,7 +234,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();
+        __syncthreads();   // everyone is done reading this tile
+        if (more) {
+            TA::store(a0, a1, a2, a3, sA, tid);
+            TB::store(b0, b1, b2, b3, sB, tid);
+            __syncthreads();
+        }
     }
 
     if (AL == 1 && do_cs && m0 + tid < a.M)

@@ -53,8 +53,13 @@ struct ProjArgs {
     int tiles_per_split;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair (RNE): one v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    return (unsigned)sv_f2bf(a) | ((unsigned)sv_f2bf(b) << 16);
+    const f32x2 v = {a, b};
+    const bf16v2 h = __builtin_convertvector(v, bf16v2);
+    return *reinterpret_cast<const unsigned*>(&h);
 }
 
 template <int MODE>
@@ -154,16 +159,20 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
         const unsigned short* sT = sY + BY * YLD;
         const float* sK = reinterpret_cast<const float*>(smem + buf * STAGE_BYTES + STAGE_ELEMS * 2);
 
+        // accumulator rows of a 32x32 tile: y = (r&3) + 8*(r>>2) + 4*lh  -> groups of 4 consecutive y.
+        // Program order per tile (2 sub-tiles of 32 y): G1(s0) G1(s1) | P(s0) G2(s0) | P(s1) G2(s1) (FWD: softmax
+        // instead of P/G2): the VALU work of one sub-tile is independent of the MFMAs next to it, so the
+        // scheduler can run it under them (MFMA and VALU are separate pipes).
+        f32x16 c1[2][2];
 #pragma unroll
-        for (int sub = 0; sub < BY / 32; ++sub) {
-            // accumulator rows of a 32x32 tile: y = (r&3) + 8*(r>>2) + 4*lh  -> groups of 4 consecutive y
-            f32x16 c1[2];
+        for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 kv = *reinterpret_cast<const float4*>(sK + sub * 32 + 8 * g + 4 * lh);
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    c1[b][4 * g + 0] = kv.x; c1[b][4 * g + 1] = kv.y; c1[b][4 * g + 2] = kv.z; c1[b][4 * g + 3] = kv.w;
+                    c1[sub][b][4 * g + 0] = kv.x; c1[sub][b][4 * g + 1] = kv.y;
+                    c1[sub][b][4 * g + 2] = kv.z; c1[sub][b][4 * g + 3] = kv.w;
                 }
             }
 #pragma unroll
@@ -171,19 +180,22 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
                 const bf16x8 ya = *reinterpret_cast<const bf16x8*>(sY + (sub * 32 + li) * YLD + 16 * s + 8 * lh);
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    c1[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xf[b][s], c1[b], 0, 0, 0);
+                    c1[sub][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xf[b][s], c1[sub][b], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
             if (MODE == MODE_FWD) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    float tm = c1[b][0];
+                    float tm = c1[sub][b][0];
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, c1[b][r]);
+                    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, c1[sub][b][r]);
                     const float mn = fmaxf(run_m[b], tm);
                     const float mnl = mn * LOG2E;
                     float acc = run_l[b] * __builtin_amdgcn_exp2f((run_m[b] - mn) * LOG2E);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc += __builtin_amdgcn_exp2f(fmaf(c1[b][r], LOG2E, -mnl));
+                    for (int r = 0; r < 16; ++r) acc += __builtin_amdgcn_exp2f(fmaf(c1[sub][b][r], LOG2E, -mnl));
                     run_l[b] = acc;
                     run_m[b] = mn;
                 }
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
                 for (int b = 0; b < 2; ++b) {
                     float p[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(c1[b][r], LOG2E, kxv[b]));
+                    for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(c1[sub][b][r], LOG2E, kxv[b]));
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
                         uint4 u;
