@@ -18,6 +18,8 @@
 //              (336 registers per lane), h / dgh exchanged through a ping-pong bf16 LDS image: ONE
 //              barrier per timestep.
 //
+// Every per-row output buffer must have R + 1 rows: row R is a trash row that absorbs the stores of
+// inactive users in the branch-free bf16 kernels.
 // Saved for backward, per row: gates4 [R][224][4] = (r, z, n, gh_n) interleaved (one 16-byte access
 // per owned element), hs [R][224], hprev [R][224] (= h_{t-1}, the B operand of the dW_hh GEMM).
 #include "common.h"
@@ -336,12 +338,25 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
 #pragma unroll
         for (int r = 0; r < 4; ++r) hreg[q][r] = 0.f;
 
+    // The step body is ONE basic block: loads are clamped, stores of inactive users go to a trash row
+    // (row R, allocated by the caller), the matmul also runs at t = 0 (h = 0), so the scheduler is free to
+    // run the gate math of one tile under the MFMAs of the next.  Tile-major MFMA order makes the
+    // accumulators of tile q complete while tile q+1 is still in the pipe.
+    const int trash = a.row_off[a.Tmax];
+    int na = a.nact[0];
+    int rbase = a.row_off[0] + u0;
     for (int t = 0; t < a.Tmax; ++t) {
-        const int na = a.nact[t];
         if (na <= u0) break;
-        const int rbase = a.row_off[t] + u0;
         const unsigned short* hcur = h_bf + (t & 1) * (MB * HLDB);
         unsigned short* hnxt = h_bf + ((t + 1) & 1) * (MB * HLDB);
+        // next step's scalars: fetched now, consumed after the barrier
+        const int tn = (t + 1 < a.Tmax) ? t + 1 : t;
+        const int na_next = (t + 1 < a.Tmax) ? a.nact[tn] : 0;
+        const int rbase_next = a.row_off[tn] + u0;
+
+        int rowv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowv[r] = (u0 + 4 * lk + r < na) ? rbase + 4 * lk + r : trash;
 
         // input-side gates of this step: issued before the matmul so they land behind it
         float gi[NQ][4][3];
@@ -349,51 +364,46 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = 4 * lk + r;
-                const bool act = (u0 + m) < na;
-                const float* gp = a.gi + (size_t)(rbase + (act ? m : 0)) * SV_G + 16 * (wave + 4 * q) + ln;
+                const float* gp = a.gi + (size_t)(rowv[r] == trash ? rbase : rowv[r]) * SV_G + 16 * (wave + 4 * q) + ln;
 #pragma unroll
                 for (int g = 0; g < 3; ++g) gi[q][r][g] = gp[g * SV_HP];
             }
 
+        bf16x8 A[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) A[s] = *reinterpret_cast<const bf16x8*>(hcur + ln * HLDB + 32 * s + 8 * lk);
         f32x4 acc[NQ][3];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[q][g] = (f32x4){bias[q][g], bias[q][g], bias[q][g], bias[q][g]};
-        if (t > 0) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bf16x8 A = *reinterpret_cast<const bf16x8*>(hcur + ln * HLDB + 32 * s + 8 * lk);
+        for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-                for (int q = 0; q < NR; ++q)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        acc[q][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, W[q][g][s], acc[q][g], 0, 0, 0);
-#pragma unroll
-                for (int ql = 0; ql < NL; ++ql)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wl + ((ql * 3 + g) * KS + s) * 512);
-                        acc[NR + ql][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, wv, acc[NR + ql][g], 0, 0, 0);
-                    }
-            }
+                for (int g = 0; g < 3; ++g) {
+                    bf16x8 wv;
+                    if (q < NR)
+                        wv = W[q < NR ? q : 0][g][s];
+                    else
+                        wv = *reinterpret_cast<const bf16x8*>(wl + (((q - NR) * 3 + g) * KS + s) * 512);
+                    acc[q][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], wv, acc[q][g], 0, 0, 0);
+                }
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int j = 16 * (wave + 4 * q) + ln;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = 4 * lk + r;
-                if (u0 + m < na) {
-                    const size_t row = (size_t)(rbase + m);
-                    const float hn = gate_fwd<true>(a, row, j, gi[q][r][0], gi[q][r][1], gi[q][r][2], acc[q][0][r],
-                                              acc[q][1][r], acc[q][2][r], hreg[q][r]);
-                    hreg[q][r] = hn;
-                    hnxt[m * HLDB + j] = sv_f2bf(hn);
-                }
+                const float hn = gate_fwd<true>(a, (size_t)rowv[r], j, gi[q][r][0], gi[q][r][1], gi[q][r][2],
+                                                acc[q][0][r], acc[q][1][r], acc[q][2][r], hreg[q][r]);
+                hreg[q][r] = hn;
+                hnxt[(4 * lk + r) * HLDB + j] = sv_f2bf(hn);
             }
         }
+        na = na_next;
+        rbase = rbase_next;
         __syncthreads();  // h_t published (ping-pong image: the next step writes the other buffer)
     }
 }
@@ -443,10 +453,15 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh[q][r] = 0.f;
 
+    const int trash = a.row_off[a.Tmax];
     for (int t = Tw - 1; t >= 0; --t) {
         const int na = a.nact[t];
         const int rbase = a.row_off[t] + u0;
         unsigned short* gcur = g_bf + (t & 1) * (MB * GLDB);
+        // one basic block: clamped loads, inactive users compute with d = 0 and store to the trash row
+        int rowv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowv[r] = (u0 + 4 * lk + r < na) ? rbase + 4 * lk + r : trash;
         float carry[NQ][4];
         float4 sg[NQ][4];
         float shp[NQ][4], sdh[NQ][4];
@@ -454,8 +469,7 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = 4 * lk + r;
-                const size_t e = (size_t)(rbase + ((u0 + m < na) ? m : 0)) * SV_HP + 16 * (wave + 4 * q) + ln;
+                const size_t e = (size_t)(rowv[r] == trash ? rbase : rowv[r]) * SV_HP + 16 * (wave + 4 * q) + ln;
                 sg[q][r] = *reinterpret_cast<const float4*>(a.gates4 + e * 4);
                 shp[q][r] = a.hprev[e];
                 sdh[q][r] = a.dhs[e];
@@ -465,13 +479,10 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
             const int j = 16 * (wave + 4 * q) + ln;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                float drp, dzp, dnr;
+                const float d = (rowv[r] == trash) ? 0.f : dh[q][r] + sdh[q][r];
+                carry[q][r] = gate_bwd(a, (size_t)rowv[r], j, d, sg[q][r], shp[q][r], drp, dzp, dnr);
                 const int m = 4 * lk + r;
-                float drp = 0.f, dzp = 0.f, dnr = 0.f;
-                carry[q][r] = 0.f;
-                if (u0 + m < na) {
-                    const size_t row = (size_t)(rbase + m);
-                    carry[q][r] = gate_bwd(a, row, j, dh[q][r] + sdh[q][r], sg[q][r], shp[q][r], drp, dzp, dnr);
-                }
                 gcur[m * GLDB + j] = sv_f2bf(drp);
                 gcur[m * GLDB + SV_HP + j] = sv_f2bf(dzp);
                 gcur[m * GLDB + 2 * SV_HP + j] = sv_f2bf(dnr);
