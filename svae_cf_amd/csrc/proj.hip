@@ -267,6 +267,157 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward, software-pipelined: the online-softmax VALU work of tile t-1 (registers only) is issued in the
+// same basic block as the MFMAs of tile t, so the two pipes overlap inside the single wave per SIMD.
+// ------------------------------------------------------------------------------------------------
+constexpr int FSTAGE_BYTES = BY * YLD * 2 + BY * 4;
+
+__device__ __forceinline__ void fwd_g1(f32x16 (&c)[2][2], const bf16x8 (&xf)[2][KS1], const unsigned short* sY,
+                                       const float* sK, int li, int lh) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 kv = *reinterpret_cast<const float4*>(sK + sub * 32 + 8 * g + 4 * lh);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                c[sub][b][4 * g + 0] = kv.x; c[sub][b][4 * g + 1] = kv.y;
+                c[sub][b][4 * g + 2] = kv.z; c[sub][b][4 * g + 3] = kv.w;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            const bf16x8 ya = *reinterpret_cast<const bf16x8*>(sY + (sub * 32 + li) * YLD + 16 * s + 8 * lh);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) c[sub][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xf[b][s], c[sub][b], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void fwd_softmax(const f32x16 (&c)[2][2], float (&run_m)[2], float (&run_l)[2]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        float tm = fmaxf(c[0][b][0], c[1][b][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(c[0][b][r], c[1][b][r]));
+        const float mn = fmaxf(run_m[b], tm);
+        const float mnl = mn * LOG2E;
+        float acc0 = run_l[b] * __builtin_amdgcn_exp2f((run_m[b] - mn) * LOG2E), acc1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0 += __builtin_amdgcn_exp2f(fmaf(c[0][b][r], LOG2E, -mnl));
+            acc1 += __builtin_amdgcn_exp2f(fmaf(c[1][b][r], LOG2E, -mnl));
+        }
+        run_l[b] = acc0 + acc1;
+        run_m[b] = mn;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void proj_fwd_kernel(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int xt = blockIdx.x / NSPLIT, split = blockIdx.x % NSPLIT;
+    const int x0 = xt * BX + wave * 64;
+    const int ntiles = (a.ny + BY - 1) / BY;
+    const int t_begin = split * a.tiles_per_split;
+    int t_end = t_begin + a.tiles_per_split;
+    if (t_end > ntiles) t_end = ntiles;
+
+    bf16x8 xf[2][KS1];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int x = x0 + 32 * b + li;
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (x < a.nx) v = *reinterpret_cast<const bf16x8*>(a.X + (size_t)x * KP + 16 * s + 8 * lh);
+            xf[b][s] = v;
+        }
+    }
+    float run_m[2] = {NEG_BIG, NEG_BIG}, run_l[2] = {0.f, 0.f};
+    uint4 sy0, sy1, sy2, sy3, sy4;
+    float skv = 0.f;
+#define SV_FLOAD(t_)                                                                                     \
+    {                                                                                                    \
+        const int y0_ = (t_) * BY;                                                                       \
+        sy0 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid) / 20) * KP + 8 * ((tid) % 20));            \
+        sy1 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid + 256) / 20) * KP + 8 * ((tid + 256) % 20)); \
+        sy2 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid + 512) / 20) * KP + 8 * ((tid + 512) % 20)); \
+        sy3 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid + 768) / 20) * KP + 8 * ((tid + 768) % 20)); \
+        sy4 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid + 1024) / 20) * KP + 8 * ((tid + 1024) % 20)); \
+        if (tid < BY) skv = a.ky[y0_ + tid];                                                             \
+    }
+#define SV_FSTORE(buf_)                                                                                  \
+    {                                                                                                    \
+        unsigned short* sY_ = reinterpret_cast<unsigned short*>(smem + (buf_) * FSTAGE_BYTES);           \
+        *reinterpret_cast<uint4*>(sY_ + ((tid) / 20) * YLD + 8 * ((tid) % 20)) = sy0;                    \
+        *reinterpret_cast<uint4*>(sY_ + ((tid + 256) / 20) * YLD + 8 * ((tid + 256) % 20)) = sy1;        \
+        *reinterpret_cast<uint4*>(sY_ + ((tid + 512) / 20) * YLD + 8 * ((tid + 512) % 20)) = sy2;        \
+        *reinterpret_cast<uint4*>(sY_ + ((tid + 768) / 20) * YLD + 8 * ((tid + 768) % 20)) = sy3;        \
+        *reinterpret_cast<uint4*>(sY_ + ((tid + 1024) / 20) * YLD + 8 * ((tid + 1024) % 20)) = sy4;      \
+        if (tid < BY) reinterpret_cast<float*>(smem + (buf_) * FSTAGE_BYTES + BY * YLD * 2)[tid] = skv;  \
+    }
+// interleave directive for one step: LDS reads up front, then every MFMA carries ~9 VALU of the softmax
+#define SV_FWD_SCHED                                                          \
+    {                                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 14; ++i_) {                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);                \
+        }                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 26; ++i_) {                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);                \
+        }                                                                     \
+    }
+#define SV_FSTEP(CN, CO, t_, SOFTMAX)                                                                    \
+    {   /* one basic block: the next tile's loads / LDS stores are unconditional (index clamped) */      \
+        const int buf_ = ((t_) - t_begin) & 1;                                                           \
+        const int tn_ = ((t_) + 1 < t_end) ? (t_) + 1 : (t_);                                            \
+        SV_FLOAD(tn_)                                                                                    \
+        fwd_g1(CN, xf, reinterpret_cast<const unsigned short*>(smem + buf_ * FSTAGE_BYTES),              \
+               reinterpret_cast<const float*>(smem + buf_ * FSTAGE_BYTES + BY * YLD * 2), li, lh);       \
+        if (SOFTMAX) {                                                                                   \
+            fwd_softmax(CO, run_m, run_l);                                                               \
+            SV_FWD_SCHED                                                                                 \
+        }                                                                                                \
+        SV_FSTORE(buf_ ^ 1)                                                                              \
+        __syncthreads();                                                                                 \
+    }
+
+    f32x16 cA[2][2], cB[2][2];
+    if (t_begin < t_end) {      // block-uniform
+        SV_FLOAD(t_begin)
+        SV_FSTORE(0)
+        __syncthreads();
+        SV_FSTEP(cA, cB, t_begin, false)        // prologue: tile t_begin -> cA, nothing to reduce yet
+        int t = t_begin + 1;
+        for (; t + 1 < t_end; t += 2) {
+            SV_FSTEP(cB, cA, t, true)           // MFMAs of tile t   -> cB, softmax of the tile held in cA
+            SV_FSTEP(cA, cB, t + 1, true)       // MFMAs of tile t+1 -> cA, softmax of tile t (cB)
+        }
+        if (t < t_end) {
+            SV_FSTEP(cB, cA, t, true)
+            fwd_softmax(cB, run_m, run_l);
+        } else {
+            fwd_softmax(cA, run_m, run_l);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const float om = __shfl_xor(run_m[b], 32, 64);
+        const float ol = __shfl_xor(run_l[b], 32, 64);
+        const float mn = fmaxf(run_m[b], om);
+        const float l = run_l[b] * __builtin_amdgcn_exp2f((run_m[b] - mn) * LOG2E) +
+                        ol * __builtin_amdgcn_exp2f((om - mn) * LOG2E);
+        const int x = x0 + 32 * b + li;
+        if (lh == 0 && x < a.nx) reinterpret_cast<float2*>(a.out)[(size_t)split * a.nx + x] = make_float2(mn, l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // operand preparation
 // ------------------------------------------------------------------------------------------------
 // fp32 [n][160] -> bf16 row-major copy [n_pad][160] and transposed copy [160][ldt]; optional "ones"
@@ -499,7 +650,12 @@ extern "C" int svae_proj_nll_fwd(const void* h2b, const void* w3b, const float* 
     ProjArgs a{(const unsigned short*)h2b, (const unsigned short*)w3b, nullptr, nullptr, ky_items, part, R, I, 0, 0};
     const int ntiles = (I + BY - 1) / BY;
     a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
-    if (int e = launch_proj<MODE_FWD>(a, (hipStream_t)stream)) return e;
+    {
+        const int lds = 2 * FSTAGE_BYTES;
+        const int xt = (a.nx + BX - 1) / BX;
+        hipLaunchKernelGGL(proj_fwd_kernel, dim3(xt * NSPLIT), dim3(256), lds, (hipStream_t)stream, a);
+        SV_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(proj_fwd_finish_kernel, dim3((R_pad + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (const float2*)part, h2, w3, b3, tgt, w_nll, R, K, nll_row, lse, kx_rows, ky_rows, R_pad);
     SV_LAUNCH_CHECK();
