@@ -88,7 +88,8 @@ def main():
     for _ in range(args.warmup):
         eng.train_step(plans[step % len(plans)], 0.01, seed=1234)
         step += 1
-    tags = ["proj_fwd", "proj_bwd", "proj_dw", "proj_dx", "softmax_nll", "gru_fwd", "gru_bwd"]
+    tags = ["proj_fwd", "proj_dw_fused", "proj_dw_finish", "proj_dh_fused", "proj_dh_finish", "proj_dw", "proj_dx",
+            "softmax_nll", "gru_fwd", "gru_bwd"]
     eng.prof = {t: [] for t in tags}
     barrier()
     t0 = time.perf_counter()
@@ -117,33 +118,35 @@ def main():
             kt[tag] = float(np.mean([a.elapsed_time(b) for a, b in evs]))     # ms
     eng.prof = None
     rows_step = rows_done / args.steps
-    IP = eng.IP
-    flops_gemm = 2.0 * rows_step * IP * 160          # one projection-sized GEMM (padded K = 160)
-    dominant = max(kt, key=kt.get) if kt else None
-    roofline = None
-    if dominant is not None:
-        ms = kt[dominant]
-        if dominant.startswith("proj_"):
-            ach = flops_gemm / (ms * 1e-3) / 1e12
-            peak = PEAK[args.prec]
-            roofline = dict(bound="mfma", kernel=dominant, achieved=ach, peak=peak, unit="TFLOP/s",
-                            frac=ach / peak, traffic=None, avg_ms=ms)
-        elif dominant == "softmax_nll":
-            byts = rows_step * IP * 4 * 2 + rows_step * 4 * 4
-            ach = byts / (ms * 1e-3) / 1e9
-            roofline = dict(bound="hbm", kernel=dominant, achieved=ach, peak=PEAK["hbm"], unit="GB/s",
-                            frac=ach / PEAK["hbm"], traffic=None, avg_ms=ms)
+    # Algorithmic work per launch: one projection-sized contraction = 300*I flop per row; the
+    # fused forward kernel does one, each fused backward kernel two (logit recompute + gradient GEMM); the
+    # GRU recurrence 2*200*600 flop per row (forward) and twice that in backward (dgh W_hh only: same count).
+    proj_flop = 300.0 * I * rows_step
+    work = {
+        "proj_fwd": ("mfma", proj_flop), "proj_dh_fused": ("mfma", 2 * proj_flop),
+        "proj_dw_fused": ("mfma", 2 * proj_flop), "proj_dw": ("mfma", proj_flop), "proj_dx": ("mfma", proj_flop),
+        "gru_fwd": ("mfma", 240000.0 * rows_step), "gru_bwd": ("mfma", 240000.0 * rows_step),
+        "softmax_nll": ("hbm", rows_step * I * 4 * 2 + rows_step * 4 * 4),
+    }
+    rooflines = {}
+    for tag, ms in kt.items():
+        if tag not in work:
+            continue
+        bound, amount = work[tag]
+        if bound == "mfma":
+            ach, peak, unit = amount / (ms * 1e-3) / 1e12, PEAK[args.prec], "TFLOP/s"
         else:
-            fl = 2.0 * rows_step * 224 * 672
-            ach = fl / (ms * 1e-3) / 1e12
-            peak = PEAK["fp32"]
-            roofline = dict(bound="mfma", kernel=dominant, achieved=ach, peak=peak, unit="TFLOP/s",
-                            frac=ach / peak, traffic=None, avg_ms=ms)
+            ach, peak, unit = amount / (ms * 1e-3) / 1e9, PEAK["hbm"], "GB/s"
+        rooflines[tag] = dict(bound=bound, kernel=tag, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
+                              traffic=None, avg_ms=ms)
+    # the dominant kernel = the tagged kernel with the largest share of the step
+    dominant = max(rooflines, key=lambda k: rooflines[k]["avg_ms"]) if rooflines else None
+    roofline = rooflines.get(dominant)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import svae_torch as TP           # checker / baseline leg only
-        cb = TP.time_cpu_baseline(users[:80], I, next_k=4, warmup=2, budget_s=15.0, max_users=70)
+        cb = TP.time_cpu_baseline(users[:1200], I, next_k=4, warmup=3, budget_s=20.0, max_users=1000)
         cpu = dict(value=cb["value"], unit="sequences/s", cores=cb["cores"], kind="port",
                    sample="%d users of the same synthetic ML-20M-shaped set, notebook-style B=1 fwd+bwd+Adam "
                           "(dense fp32, torch CPU), %.1f s" % (cb["users"], cb["seconds"]))
@@ -158,7 +161,7 @@ def main():
                                    "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam" % B,
                        "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "parallelism": "dp%d" % world,
                        "final_loss": loss},
-            "kernel_ms": kt, "roofline": roofline, "cpu_baseline": cpu,
+            "kernel_ms": kt, "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -87,7 +87,10 @@ int svae_loss_reduce(const float* nll_row, const float* kl_row, const float* w_n
 /* ---- fused projection + log-softmax + NLL (bf16 MFMA path; logits are never materialised) -----------
  * Replace Decoder.linear2 nb:710 + F.log_softmax nb:802 + likelihood nb:805-808 and their autograd.
  * svae_proj_prep makes the bf16 operand copies (dst [n_pad][160], dstT [160][ldt]; ones_col >= 0 sets
- * that column to 1.0); svae_proj_bias_consts the per-item constants.  See csrc/proj.hip. */
+ * that column to 1.0); svae_proj_bias_consts the per-item constants.  See csrc/proj.hip.
+ * svae_proj_nll_bwd parts (bit mask, 15 = everything): 1 weight-gradient kernel, 2 its finish (sparse target
+ * part, writes gw3/gb3), 4 hidden-gradient kernel, 8 its finish (writes dd1); pieces share `slabs` and must
+ * be enqueued in that order -- the split exists so a profiler can bracket one kernel. */
 int svae_proj_nsplit(void);
 int svae_proj_tile(void);
 int svae_proj_prep(const float* src, void* dst, void* dstT, int n, int n_pad, int ldt, int ones_col, void* stream);
@@ -99,7 +102,7 @@ int svae_proj_nll_bwd(const void* h2b, const void* h2tb, int ldt_rows, const voi
                       int ldt_items, const float* kx_rows, const float* ky_rows, const float* kx_items,
                       const float* ky_items, const float* h2, const float* w3, const int* tgt, const float* w_nll,
                       const int* occ_off, const int* occ_row, int R, int I, int I_pad, int K, float* slabs,
-                      float* dd1, float* gw3, float* gb3, void* stream);
+                      float* dd1, float* gw3, float* gb3, int parts, void* stream);
 
 /* ---- Adam with L2 weight decay on one flat buffer ----------------------------------------------------
  * Replaces optimizer.step() nb:1206 with torch.optim.Adam(weight_decay=5e-3) nb:1260-1263 (and the

@@ -39,7 +39,7 @@ SIGNATURES = {
     "svae_proj_bias_consts": [_P, _P, _P, _I, _I, _P],
     "svae_proj_nll_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "svae_proj_nll_bwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
-                          _P, _P, _P, _P, _P],
+                          _P, _P, _P, _P, _I, _P],
     "svae_proj_nsplit": [],
     "svae_proj_tile": [],
     "svae_check_device": [],

@@ -670,30 +670,38 @@ extern "C" int svae_proj_nll_bwd(const void* h2b, const void* h2tb, int ldt_rows
                                  int ldt_items, const float* kx_rows, const float* ky_rows, const float* kx_items,
                                  const float* ky_items, const float* h2, const float* w3, const int* tgt,
                                  const float* w_nll, const int* occ_off, const int* occ_row, int R, int I, int I_pad,
-                                 int K, float* slabs, float* dd1, float* gw3, float* gb3, void* stream) {
+                                 int K, float* slabs, float* dd1, float* gw3, float* gb3, int parts, void* stream) {
     SV_CHECK_ARG(h2b && h2tb && w3b && w3tb && kx_rows && ky_rows && kx_items && ky_items && h2 && w3 && tgt &&
                      w_nll && occ_off && occ_row && slabs && dd1 && gw3 && gb3, "svae_proj_nll_bwd: null pointer");
-    SV_CHECK_ARG(R > 0 && I > 0 && I_pad >= I && K >= 1, "svae_proj_nll_bwd: bad shape");
+    SV_CHECK_ARG(R > 0 && I > 0 && I_pad >= I && K >= 1 && parts > 0 && parts < 16, "svae_proj_nll_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    {   // dL/dW3, dL/db3:  X = items, Y = rows
+    // parts: 1 = weight-gradient kernel, 2 = its finish, 4 = hidden-gradient kernel, 8 = its finish (15 = all;
+    // the pieces share `slabs`, so they must be enqueued in this order on one stream)
+    if (parts & 3) {   // dL/dW3, dL/db3:  X = items, Y = rows
         ProjArgs a{(const unsigned short*)w3b, (const unsigned short*)h2b, (const unsigned short*)h2tb, kx_items,
                    ky_rows, slabs, I, R, ldt_rows, 0};
         const int ntiles = (R + BY - 1) / BY;
         a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
-        if (int e = launch_proj<MODE_DW>(a, st)) return e;
-        hipLaunchKernelGGL(proj_dw_finish_kernel, dim3(I_pad), dim3(256), 0, st, slabs, h2, w_nll, occ_off,
-                           occ_row, gw3, gb3, I, I_pad);
-        SV_LAUNCH_CHECK();
+        if (parts & 1)
+            if (int e = launch_proj<MODE_DW>(a, st)) return e;
+        if (parts & 2) {
+            hipLaunchKernelGGL(proj_dw_finish_kernel, dim3(I_pad), dim3(256), 0, st, slabs, h2, w_nll, occ_off,
+                               occ_row, gw3, gb3, I, I_pad);
+            SV_LAUNCH_CHECK();
+        }
     }
-    {   // dL/dh2:  X = rows, Y = items
+    if (parts & 12) {   // dL/dh2:  X = rows, Y = items
         ProjArgs a{(const unsigned short*)h2b, (const unsigned short*)w3b, (const unsigned short*)w3tb, kx_rows,
                    ky_items, slabs, R, I, ldt_items, 0};
         const int ntiles = (I + BY - 1) / BY;
         a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
-        if (int e = launch_proj<MODE_DH>(a, st)) return e;
-        hipLaunchKernelGGL(proj_dh_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, st, slabs, w3, tgt, w_nll, h2, dd1,
-                           R, K);
-        SV_LAUNCH_CHECK();
+        if (parts & 4)
+            if (int e = launch_proj<MODE_DH>(a, st)) return e;
+        if (parts & 8) {
+            hipLaunchKernelGGL(proj_dh_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, st, slabs, w3, tgt, w_nll, h2,
+                               dd1, R, K);
+            SV_LAUNCH_CHECK();
+        }
     }
     return 0;
 }

@@ -273,15 +273,21 @@ class SVAEEngine:
             if plan.occ_off is None:
                 raise ValueError("fused mode needs build_plan(..., total_items=I)")
             Rp = (R + 63) // 64 * 64
-            ev = self._tic("proj_bwd")
-            _lib.call("svae_proj_nll_bwd", w["h2b"].data_ptr(), w["h2tb"].data_ptr(), Rp, self.w3b.data_ptr(),
-                      self.w3tb.data_ptr(), self.IPAD, w["kx_rows"].data_ptr(), w["ky_rows"].data_ptr(),
-                      self.kx_items.data_ptr(), self.ky_items.data_ptr(), w["d1"].data_ptr(),
-                      self.P("decoder.linear2.weight").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
-                      plan.occ_off.data_ptr(), plan.occ_row.data_ptr(), R, I, IP, plan.K, w["pslabs"].data_ptr(),
-                      w["dd1"].data_ptr(), self.Gv("decoder.linear2.weight").data_ptr(),
-                      self.Gv("decoder.linear2.bias").data_ptr(), st)
-            self._toc("proj_bwd", ev)
+            args = (w["h2b"].data_ptr(), w["h2tb"].data_ptr(), Rp, self.w3b.data_ptr(),
+                    self.w3tb.data_ptr(), self.IPAD, w["kx_rows"].data_ptr(), w["ky_rows"].data_ptr(),
+                    self.kx_items.data_ptr(), self.ky_items.data_ptr(), w["d1"].data_ptr(),
+                    self.P("decoder.linear2.weight").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
+                    plan.occ_off.data_ptr(), plan.occ_row.data_ptr(), R, I, IP, plan.K, w["pslabs"].data_ptr(),
+                    w["dd1"].data_ptr(), self.Gv("decoder.linear2.weight").data_ptr(),
+                    self.Gv("decoder.linear2.bias").data_ptr())
+            if self.prof is None:
+                _lib.call("svae_proj_nll_bwd", *args, 15, st)
+            else:       # profiling: bracket each kernel of the call on its own
+                for bit, tag in ((1, "proj_dw_fused"), (2, "proj_dw_finish"), (4, "proj_dh_fused"),
+                                 (8, "proj_dh_finish")):
+                    ev = self._tic(tag)
+                    _lib.call("svae_proj_nll_bwd", *args, bit, st)
+                    self._toc(tag, ev)
             self._bucket(0)
         else:
             dl = w["logits"]
