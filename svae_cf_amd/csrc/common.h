@@ -21,6 +21,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 
 extern thread_local char g_svae_err[512];
 int svae_fail(int code, const char* fmt, ...);

@@ -292,12 +292,12 @@ __device__ __forceinline__ bf16x8 load_w8(const float* p) {
 // (252) and the fourth tile of waves 0 and 1 lives in LDS in fragment order (lane-linear 16-byte reads,
 // conflict-free): 2 waves x 21 fragments x 1 KiB = 42 KiB.
 constexpr int WL_FRAGS = 21;                       // fragments of the LDS-resident tile (fwd: 3 gates x 7; bwd: 21 k-steps)
-constexpr int WL_ELEMS = 2 * WL_FRAGS * 64 * 8;    // bf16 elements
 
 // Forward keeps only TWO tiles per wave in registers (168): the gate math (expf / tanhf expansions, the gi
 // prefetch, h state) needs the rest of the arch VGPRs.  LDS-resident forward tiles: waves 0,1 two each,
 // waves 2,3 one each = 6 tiles x 21 KiB = 126 KiB.
 constexpr int WLF_ELEMS = 6 * WL_FRAGS * 64 * 8;
+constexpr int WLB_ELEMS = 5 * WL_FRAGS * 64 * 8;   // backward: 5 LDS-resident tiles (see gru_bwd_bf16_kernel)
 
 template <int NQ>  // number of hidden tiles this wave owns (4 for waves 0,1; 3 for waves 2,3)
 __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned short* h_bf, unsigned short* w_lds,
@@ -422,27 +422,28 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_bf16_kernel(GruArgs a) {
         gru_fwd_bf16_body<3>(a, h_bf, w_lds, wave, lane);
 }
 
-template <int NQ>
+template <int NQ, int NR>  // hidden tiles owned by this wave / how many of them stay in registers
 __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned short* g_bf, unsigned short* w_lds,
-                                                  int wave, int lane) {
+                                                  int slot0, int wave, int lane) {
     const int u0 = blockIdx.x * MB;
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_G / 32;  // 21 k-steps
+    constexpr int NL = NQ - NR;    // tiles in LDS (fragment order, lane-linear 16-byte reads)
 
     // B operand of dh_{t-1} = dgh W_hh: B[k = gate column c][n = hidden j'] = W_hh[c][j'] = whh_t[j'][c]
-    bf16x8 W[3][KS];
+    bf16x8 W[NR][KS];
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < NR; ++q)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             W[q][s] = load_w8(a.whh + (size_t)(16 * (wave + 4 * q) + ln) * SV_G + 32 * s + 8 * lk);
-    unsigned short* wl = w_lds + (size_t)wave * (WL_FRAGS * 64 * 8) + lane * 8;
-    if (NQ == 4) {
+    unsigned short* wl = w_lds + (size_t)slot0 * (WL_FRAGS * 64 * 8) + lane * 8;
+#pragma unroll
+    for (int ql = 0; ql < NL; ++ql)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-            *reinterpret_cast<bf16x8*>(wl + s * 512) =
-                load_w8(a.whh + (size_t)(16 * (wave + 12) + ln) * SV_G + 32 * s + 8 * lk);
-    }
+            *reinterpret_cast<bf16x8*>(wl + (ql * KS + s) * 512) =
+                load_w8(a.whh + (size_t)(16 * (wave + 4 * (NR + ql)) + ln) * SV_G + 32 * s + 8 * lk);
 
     int Tw = 0;
     while (Tw < a.Tmax && a.nact[Tw] > u0) ++Tw;
@@ -454,26 +455,29 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
         for (int r = 0; r < 4; ++r) dh[q][r] = 0.f;
 
     const int trash = a.row_off[a.Tmax];
+    // Saved forward values of a step are fetched one step ahead (issued right after the barrier, consumed
+    // after the matmul of the step before), so their L2 / HBM latency sits under the MFMAs and not in the
+    // recurrence's critical path.  Clamped loads; inactive users compute with d = 0 and store to the trash row.
+    float4 sg[NQ][4];
+    float shp[NQ][4], sdh[NQ][4];
+    int rowv[4];
+#define SV_GRU_BWD_FETCH(t_)                                                                                \
+    {                                                                                                       \
+        const int na_ = a.nact[t_];                                                                         \
+        const int rbase_ = a.row_off[t_] + u0;                                                              \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) rowv[r] = (u0 + 4 * lk + r < na_) ? rbase_ + 4 * lk + r : trash; \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
+                const size_t e = (size_t)(rowv[r] == trash ? rbase_ : rowv[r]) * SV_HP + 16 * (wave + 4 * q) + ln; \
+                sg[q][r] = *reinterpret_cast<const float4*>(a.gates4 + e * 4);                              \
+                shp[q][r] = a.hprev[e];                                                                     \
+                sdh[q][r] = a.dhs[e];                                                                       \
+            }                                                                                               \
+    }
+    if (Tw > 0) SV_GRU_BWD_FETCH(Tw - 1)
     for (int t = Tw - 1; t >= 0; --t) {
-        const int na = a.nact[t];
-        const int rbase = a.row_off[t] + u0;
         unsigned short* gcur = g_bf + (t & 1) * (MB * GLDB);
-        // one basic block: clamped loads, inactive users compute with d = 0 and store to the trash row
-        int rowv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rowv[r] = (u0 + 4 * lk + r < na) ? rbase + 4 * lk + r : trash;
         float carry[NQ][4];
-        float4 sg[NQ][4];
-        float shp[NQ][4], sdh[NQ][4];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const size_t e = (size_t)(rowv[r] == trash ? rbase : rowv[r]) * SV_HP + 16 * (wave + 4 * q) + ln;
-                sg[q][r] = *reinterpret_cast<const float4*>(a.gates4 + e * 4);
-                shp[q][r] = a.hprev[e];
-                sdh[q][r] = a.dhs[e];
-            }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int j = 16 * (wave + 4 * q) + ln;
@@ -490,6 +494,7 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
         }
         __syncthreads();  // dgh_t published (ping-pong: step t-1 writes the other buffer)
         if (t > 0) {
+            SV_GRU_BWD_FETCH(t - 1)
             f32x4 acc[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -502,11 +507,13 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
 #pragma unroll
                 for (int s = 0; s < 7; ++s) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], W[q][s0 + s], acc[q], 0, 0, 0);
-                    if (NQ == 4) {
-                        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wl + (s0 + s) * 512);
-                        acc[NQ - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], wv, acc[NQ - 1], 0, 0, 0);
+                    for (int q = 0; q < NQ; ++q) {
+                        bf16x8 wv;
+                        if (q < NR)
+                            wv = W[q < NR ? q : 0][s0 + s];
+                        else
+                            wv = *reinterpret_cast<const bf16x8*>(wl + ((q - NR) * KS + s0 + s) * 512);
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], wv, acc[q], 0, 0, 0);
                     }
                 }
             }
@@ -516,18 +523,23 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
                 for (int r = 0; r < 4; ++r) dh[q][r] = carry[q][r] + acc[q][r];
         }
     }
+#undef SV_GRU_BWD_FETCH
 }
 
 __global__ __launch_bounds__(256, 1) void gru_bwd_bf16_kernel(GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_b[];
-    unsigned short* w_lds = smem_b;                // [2][21][64][8]
-    unsigned short* g_bf = smem_b + WL_ELEMS;      // [2][MB][GLDB]
+    unsigned short* w_lds = smem_b;                // [5][21][64][8]
+    unsigned short* g_bf = smem_b + WLB_ELEMS;     // [2][MB][GLDB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // registers vs LDS per wave: waves 0,1 own 4 tiles (2 + 2), wave 2 owns 3 (2 + 1), wave 3 owns 3 (3 + 0):
+    // the freed registers hold the one-step-ahead prefetch of the saved forward values
     if (wave < 2)
-        gru_bwd_bf16_body<4>(a, g_bf, w_lds, wave, lane);
+        gru_bwd_bf16_body<4, 2>(a, g_bf, w_lds, 2 * wave, wave, lane);
+    else if (wave == 2)
+        gru_bwd_bf16_body<3, 2>(a, g_bf, w_lds, 4, wave, lane);
     else
-        gru_bwd_bf16_body<3>(a, g_bf, w_lds, wave, lane);
+        gru_bwd_bf16_body<3, 3>(a, g_bf, w_lds, 0, wave, lane);
 }
 
 }  // namespace
@@ -573,7 +585,7 @@ extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* g
     if (prec == 0) {
         hipLaunchKernelGGL(gru_bwd_f32_kernel, grid, dim3(256), MB * GLD * sizeof(float), (hipStream_t)stream, a);
     } else {
-        const int lds = (WL_ELEMS + 2 * MB * GLDB) * sizeof(unsigned short);
+        const int lds = (WLB_ELEMS + 2 * MB * GLDB) * sizeof(unsigned short);   // 105 + 42.5 KiB
         hipError_t e = hipFuncSetAttribute((const void*)gru_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_bwd: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(gru_bwd_bf16_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);

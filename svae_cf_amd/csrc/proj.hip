@@ -53,8 +53,6 @@ struct ProjArgs {
     int tiles_per_split;
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 // two fp32 -> packed bf16 pair (RNE): one v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     const f32x2 v = {a, b};
