@@ -26,12 +26,24 @@
 
 namespace {
 
-constexpr int MB = 16;             // users per workgroup (MFMA M)
+constexpr int MB = 16;             // MFMA M: user rows of a workgroup's tiles
+constexpr int MU = 16;             // bf16 kernels: users a workgroup really owns (rows MU..15 of its tiles are
+                                   // padding).  The step is bound by the CU's 64 B/clk L1<->L2 path (gi, saved
+                                   // gates, dgi/dgh: >100 KB per step at 16 users), so halving the users per CU
+                                   // and doubling the CUs in use shortens the recurrence's critical path.
 constexpr int NJT = SV_HP / 16;    // 14 hidden-unit tiles of 16
 constexpr int HLD = SV_HP + 4;     // fp32 LDS row stride (floats) of the h image
 constexpr int GLD = SV_G + 4;      // fp32 LDS row stride (floats) of the dgh image
 constexpr int HLDB = SV_HP + 8;    // bf16 LDS row stride (elements) of the h image   (464 B rows)
 constexpr int GLDB = SV_G + 8;     // bf16 LDS row stride (elements) of the dgh image (1360 B rows)
+
+// Step scalars (nact[t], row_off[t]) are read through the constant address space: a uniform address there
+// is an s_load (lgkmcnt), not a vector load whose s_waitcnt vmcnt would also wait for every older store
+// of the step before (loads and stores retire through one in-order counter on gfx9).
+typedef __attribute__((address_space(4))) const int* sv_const_int_p;
+__device__ __forceinline__ sv_const_int_p sv_scalar_ptr(const int* p) {
+    return (sv_const_int_p)(unsigned long long)p;
+}
 
 struct GruArgs {
     const float* gi;      // [R][672]   (fwd)   input-side pre-activations incl. b_ih
@@ -302,7 +314,8 @@ constexpr int WLB_ELEMS = 5 * WL_FRAGS * 64 * 8;   // backward: 5 LDS-resident t
 template <int NQ>  // number of hidden tiles this wave owns (4 for waves 0,1; 3 for waves 2,3)
 __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned short* h_bf, unsigned short* w_lds,
                                                   int wave, int lane) {
-    const int u0 = blockIdx.x * MB;
+    const int u0 = blockIdx.x * MU;
+    const bool lane_on = 4 * (lane >> 4) < MU;   // lanes whose accumulator rows are real users
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_HP / 32;  // 7 k-steps
     constexpr int NR = 2;           // tiles in registers
@@ -342,32 +355,35 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
     // (row R, allocated by the caller), the matmul also runs at t = 0 (h = 0), so the scheduler is free to
     // run the gate math of one tile under the MFMAs of the next.  Tile-major MFMA order makes the
     // accumulators of tile q complete while tile q+1 is still in the pipe.
-    const int trash = a.row_off[a.Tmax];
-    int na = a.nact[0];
-    int rbase = a.row_off[0] + u0;
+    const sv_const_int_p nact_s = sv_scalar_ptr(a.nact), roff_s = sv_scalar_ptr(a.row_off);
+    const int trash = roff_s[a.Tmax];
+    int na = nact_s[0];
+    int rbase = roff_s[0] + u0;
     for (int t = 0; t < a.Tmax; ++t) {
         if (na <= u0) break;
         const unsigned short* hcur = h_bf + (t & 1) * (MB * HLDB);
         unsigned short* hnxt = h_bf + ((t + 1) & 1) * (MB * HLDB);
         // next step's scalars: fetched now, consumed after the barrier
         const int tn = (t + 1 < a.Tmax) ? t + 1 : t;
-        const int na_next = (t + 1 < a.Tmax) ? a.nact[tn] : 0;
-        const int rbase_next = a.row_off[tn] + u0;
+        const int na_next = (t + 1 < a.Tmax) ? nact_s[tn] : 0;
+        const int rbase_next = roff_s[tn] + u0;
 
         int rowv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rowv[r] = (u0 + 4 * lk + r < na) ? rbase + 4 * lk + r : trash;
+        for (int r = 0; r < 4; ++r) rowv[r] = (4 * lk + r < MU && u0 + 4 * lk + r < na) ? rbase + 4 * lk + r : trash;
 
         // input-side gates of this step: issued before the matmul so they land behind it
         float gi[NQ][4][3];
+        if (lane_on) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* gp = a.gi + (size_t)(rowv[r] == trash ? rbase : rowv[r]) * SV_G + 16 * (wave + 4 * q) + ln;
+                for (int r = 0; r < 4; ++r) {
+                    const float* gp = a.gi + (size_t)(rowv[r] == trash ? rbase : rowv[r]) * SV_G + 16 * (wave + 4 * q) + ln;
 #pragma unroll
-                for (int g = 0; g < 3; ++g) gi[q][r][g] = gp[g * SV_HP];
-            }
+                    for (int g = 0; g < 3; ++g) gi[q][r][g] = gp[g * SV_HP];
+                }
+        }
 
         bf16x8 A[KS];
 #pragma unroll
@@ -391,15 +407,17 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
                     acc[q][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], wv, acc[q][g], 0, 0, 0);
                 }
         }
+        if (lane_on) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int j = 16 * (wave + 4 * q) + ln;
+            for (int q = 0; q < NQ; ++q) {
+                const int j = 16 * (wave + 4 * q) + ln;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float hn = gate_fwd<true>(a, (size_t)rowv[r], j, gi[q][r][0], gi[q][r][1], gi[q][r][2],
-                                                acc[q][0][r], acc[q][1][r], acc[q][2][r], hreg[q][r]);
-                hreg[q][r] = hn;
-                hnxt[(4 * lk + r) * HLDB + j] = sv_f2bf(hn);
+                for (int r = 0; r < 4; ++r) {
+                    const float hn = gate_fwd<true>(a, (size_t)rowv[r], j, gi[q][r][0], gi[q][r][1], gi[q][r][2],
+                                                    acc[q][0][r], acc[q][1][r], acc[q][2][r], hreg[q][r]);
+                    hreg[q][r] = hn;
+                    hnxt[(4 * lk + r) * HLDB + j] = sv_f2bf(hn);
+                }
             }
         }
         na = na_next;
@@ -425,7 +443,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_bf16_kernel(GruArgs a) {
 template <int NQ, int NR>  // hidden tiles owned by this wave / how many of them stay in registers
 __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned short* g_bf, unsigned short* w_lds,
                                                   int slot0, int wave, int lane) {
-    const int u0 = blockIdx.x * MB;
+    const int u0 = blockIdx.x * MU;
+    const bool lane_on = 4 * (lane >> 4) < MU;   // lanes whose accumulator rows are real users
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_G / 32;  // 21 k-steps
     constexpr int NL = NQ - NR;    // tiles in LDS (fragment order, lane-linear 16-byte reads)
@@ -445,8 +464,9 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
             *reinterpret_cast<bf16x8*>(wl + (ql * KS + s) * 512) =
                 load_w8(a.whh + (size_t)(16 * (wave + 4 * (NR + ql)) + ln) * SV_G + 32 * s + 8 * lk);
 
+    const sv_const_int_p nact_s = sv_scalar_ptr(a.nact), roff_s = sv_scalar_ptr(a.row_off);
     int Tw = 0;
-    while (Tw < a.Tmax && a.nact[Tw] > u0) ++Tw;
+    while (Tw < a.Tmax && nact_s[Tw] > u0) ++Tw;
 
     float dh[NQ][4];
 #pragma unroll
@@ -454,7 +474,7 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh[q][r] = 0.f;
 
-    const int trash = a.row_off[a.Tmax];
+    const int trash = roff_s[a.Tmax];
     // Saved forward values of a step are fetched one step ahead (issued right after the barrier, consumed
     // after the matmul of the step before), so their L2 / HBM latency sits under the MFMAs and not in the
     // recurrence's critical path.  Clamped loads; inactive users compute with d = 0 and store to the trash row.
@@ -463,9 +483,10 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
     int rowv[4];
 #define SV_GRU_BWD_FETCH(t_)                                                                                \
     {                                                                                                       \
-        const int na_ = a.nact[t_];                                                                         \
-        const int rbase_ = a.row_off[t_] + u0;                                                              \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) rowv[r] = (u0 + 4 * lk + r < na_) ? rbase_ + 4 * lk + r : trash; \
+        const int na_ = nact_s[t_];                                                                         \
+        const int rbase_ = roff_s[t_] + u0;                                                              \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) rowv[r] = (4 * lk + r < MU && u0 + 4 * lk + r < na_) ? rbase_ + 4 * lk + r : trash; \
+        if (lane_on)                                                                                        \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
                 const size_t e = (size_t)(rowv[r] == trash ? rbase_ : rowv[r]) * SV_HP + 16 * (wave + 4 * q) + ln; \
@@ -477,7 +498,8 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
     if (Tw > 0) SV_GRU_BWD_FETCH(Tw - 1)
     for (int t = Tw - 1; t >= 0; --t) {
         unsigned short* gcur = g_bf + (t & 1) * (MB * GLDB);
-        float carry[NQ][4];
+        float carry[NQ][4] = {};
+        if (lane_on)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int j = 16 * (wave + 4 * q) + ln;
@@ -532,6 +554,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_bf16_kernel(GruArgs a) {
     unsigned short* g_bf = smem_b + WLB_ELEMS;     // [2][MB][GLDB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * MB * GLDB; i += 256) g_bf[i] = 0;   // padding rows stay zero
+    __syncthreads();
     // registers vs LDS per wave: waves 0,1 own 4 tiles (2 + 2), wave 2 owns 3 (2 + 1), wave 3 owns 3 (3 + 0):
     // the freed registers hold the one-step-ahead prefetch of the saved forward values
     if (wave < 2)
@@ -563,6 +587,7 @@ extern "C" int svae_gru_fwd(const float* gi, const float* whh, const float* bhh,
     if (prec == 0) {
         hipLaunchKernelGGL(gru_fwd_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     } else {
+        grid = dim3((B + MU - 1) / MU);
         const int lds = (WLF_ELEMS + 2 * MB * HLDB) * sizeof(unsigned short);   // 144 KiB of the CU's 160
         hipError_t e = hipFuncSetAttribute((const void*)gru_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_fwd: LDS attribute: %s", hipGetErrorString(e));
@@ -585,6 +610,7 @@ extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* g
     if (prec == 0) {
         hipLaunchKernelGGL(gru_bwd_f32_kernel, grid, dim3(256), MB * GLD * sizeof(float), (hipStream_t)stream, a);
     } else {
+        grid = dim3((B + MU - 1) / MU);
         const int lds = (WLB_ELEMS + 2 * MB * GLDB) * sizeof(unsigned short);   // 105 + 42.5 KiB
         hipError_t e = hipFuncSetAttribute((const void*)gru_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_bwd: LDS attribute: %s", hipGetErrorString(e));
