@@ -58,11 +58,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SVAE_HIP_LIB", LIB_PATH)      # explicit library path (kernel experiments)
+    if not os.path.exists(path):
         raise SvaeHipError(
             "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(or `make -C svae_cf_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "(or `make -C svae_cf_amd/csrc`).  There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -24,13 +24,20 @@
 // per owned element), hs [R][224], hprev [R][224] (= h_{t-1}, the B operand of the dW_hh GEMM).
 #include "common.h"
 
+#ifdef SV_GRU_TIMING
+__device__ unsigned long long g_gru_dbg[8];
+#define SV_TS(i_) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts_acc[i_] += now_ - ts_last; ts_last = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define SV_TS(i_)
+#endif
 namespace {
 
 constexpr int MB = 16;             // MFMA M: user rows of a workgroup's tiles
-constexpr int MU = 16;             // bf16 kernels: users a workgroup really owns (rows MU..15 of its tiles are
+constexpr int MU = 4;              // bf16 kernels: users a workgroup really owns (rows MU..15 of its tiles are
                                    // padding).  The step is bound by the CU's 64 B/clk L1<->L2 path (gi, saved
                                    // gates, dgi/dgh: >100 KB per step at 16 users), so halving the users per CU
                                    // and doubling the CUs in use shortens the recurrence's critical path.
+constexpr int MUB = 16;            // same, backward kernel
 constexpr int NJT = SV_HP / 16;    // 14 hidden-unit tiles of 16
 constexpr int HLD = SV_HP + 4;     // fp32 LDS row stride (floats) of the h image
 constexpr int GLD = SV_G + 4;      // fp32 LDS row stride (floats) of the dgh image
@@ -44,6 +51,10 @@ typedef __attribute__((address_space(4))) const int* sv_const_int_p;
 __device__ __forceinline__ sv_const_int_p sv_scalar_ptr(const int* p) {
     return (sv_const_int_p)(unsigned long long)p;
 }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned SV_BUF_FLAGS = 0x00020000u;   // raw buffer, 32-bit data format (gfx9 word 3)
+constexpr unsigned SV_BUF_OOB = 0x80000000u;     // offset of a masked lane: beyond every array (all < 2 GiB)
 
 struct GruArgs {
     const float* gi;      // [R][672]   (fwd)   input-side pre-activations incl. b_ih
@@ -290,6 +301,11 @@ __global__ __launch_bounds__(256) void gru_bwd_f32_kernel(GruArgs a) {
 // ------------------------------------------------------------------------------------------------
 // bf16 kernels: weights resident in registers
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const bf16v2 h = __builtin_convertvector((f32x2){a, b}, bf16v2);
+    return __builtin_bit_cast(unsigned, h);
+}
+
 __device__ __forceinline__ bf16x8 load_w8(const float* p) {
     const float4 lo = *reinterpret_cast<const float4*>(p);
     const float4 hi = *reinterpret_cast<const float4*>(p + 4);
@@ -305,62 +321,71 @@ __device__ __forceinline__ bf16x8 load_w8(const float* p) {
 // conflict-free): 2 waves x 21 fragments x 1 KiB = 42 KiB.
 constexpr int WL_FRAGS = 21;                       // fragments of the LDS-resident tile (fwd: 3 gates x 7; bwd: 21 k-steps)
 
-// Forward keeps only TWO tiles per wave in registers (168): the gate math (expf / tanhf expansions, the gi
-// prefetch, h state) needs the rest of the arch VGPRs.  LDS-resident forward tiles: waves 0,1 two each,
-// waves 2,3 one each = 6 tiles x 21 KiB = 126 KiB.
+// Forward: 8 waves (two per SIMD).  The step is bound by the SIMD's vector issue port (gate math), not by the
+// MFMA pipe, and with one wave per SIMD the two only overlap as far as the compiler interleaves them; with
+// two waves the hardware does it: one wave's gate math issues while the other's MFMAs execute.
+// Wave w owns hidden tiles w and w+8 (< 14): tile w in registers (84), tile w+8 in LDS in fragment order
+// (lane-linear 16-byte reads, conflict-free): 6 tiles x 21 KiB = 126 KiB.
 constexpr int WLF_ELEMS = 6 * WL_FRAGS * 64 * 8;
+constexpr int FWD_WAVES = 8;
 constexpr int WLB_ELEMS = 5 * WL_FRAGS * 64 * 8;   // backward: 5 LDS-resident tiles (see gru_bwd_bf16_kernel)
 
-template <int NQ>  // number of hidden tiles this wave owns (4 for waves 0,1; 3 for waves 2,3)
+template <int NQ>  // number of hidden tiles this wave owns (2 for waves 0..5; 1 for waves 6,7)
 __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned short* h_bf, unsigned short* w_lds,
                                                   int wave, int lane) {
     const int u0 = blockIdx.x * MU;
-    const bool lane_on = 4 * (lane >> 4) < MU;   // lanes whose accumulator rows are real users
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_HP / 32;  // 7 k-steps
-    constexpr int NR = 2;           // tiles in registers
-    constexpr int NL = NQ - NR;     // tiles in LDS
+    constexpr int NL = NQ - 1;      // tiles in LDS
 
-    bf16x8 W[NR][3][KS];
+    bf16x8 W[3][KS];
 #pragma unroll
-    for (int q = 0; q < NR; ++q)
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                W[q][g][s] = load_w8(a.whh + (size_t)(g * SV_HP + 16 * (wave + 4 * q) + ln) * SV_HP + 32 * s + 8 * lk);
-    const int slot = (NQ == 4) ? wave * 2 : 4 + (wave - 2);
-    unsigned short* wl = w_lds + (size_t)slot * (WL_FRAGS * 64 * 8) + lane * 8;
-#pragma unroll
-    for (int ql = 0; ql < NL; ++ql)
+        for (int s = 0; s < KS; ++s)
+            W[g][s] = load_w8(a.whh + (size_t)(g * SV_HP + 16 * wave + ln) * SV_HP + 32 * s + 8 * lk);
+    unsigned short* wl = w_lds + (size_t)wave * (WL_FRAGS * 64 * 8) + lane * 8;
+    if (NL > 0) {
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int s = 0; s < KS; ++s)
-                *reinterpret_cast<bf16x8*>(wl + ((ql * 3 + g) * KS + s) * 512) =
-                    load_w8(a.whh + (size_t)(g * SV_HP + 16 * (wave + 4 * (NR + ql)) + ln) * SV_HP + 32 * s + 8 * lk);
+                *reinterpret_cast<bf16x8*>(wl + (g * KS + s) * 512) =
+                    load_w8(a.whh + (size_t)(g * SV_HP + 16 * (wave + 8) + ln) * SV_HP + 32 * s + 8 * lk);
+    }
     float bias[NQ][3];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int g = 0; g < 3; ++g) bias[q][g] = a.bhh[g * SV_HP + 16 * (wave + 4 * q) + ln];
+        for (int g = 0; g < 3; ++g) bias[q][g] = a.bhh[g * SV_HP + 16 * (wave + 8 * q) + ln];
 
-    float hreg[NQ][4];
+    f32x2 hreg[NQ][2];   // h_{t-1} of the owned elements, as (r, r+1) pairs: the gate math runs on v_pk_* ops
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hreg[q][r] = 0.f;
+        for (int h = 0; h < 2; ++h) hreg[q][h] = (f32x2){0.f, 0.f};
 
     // The step body is ONE basic block: loads are clamped, stores of inactive users go to a trash row
-    // (row R, allocated by the caller), the matmul also runs at t = 0 (h = 0), so the scheduler is free to
-    // run the gate math of one tile under the MFMAs of the next.  Tile-major MFMA order makes the
-    // accumulators of tile q complete while tile q+1 is still in the pipe.
+    // (row R, allocated by the caller), the matmul also runs at t = 0 (h = 0).
     const sv_const_int_p nact_s = sv_scalar_ptr(a.nact), roff_s = sv_scalar_ptr(a.row_off);
-    const int trash = roff_s[a.Tmax];
+    // Global traffic goes through raw buffer descriptors: a lane whose accumulator rows are padding or whose
+    // user has ended gets an out-of-range offset, so its loads return 0 and its stores are dropped without
+    // a branch (the step stays one basic block) and without touching memory.
+    const unsigned R = (unsigned)roff_s[a.Tmax];
+    const __amdgpu_buffer_rsrc_t gi_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, R * (SV_G * 4u), SV_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t hs_b = __builtin_amdgcn_make_buffer_rsrc(a.hs, 0, R * (SV_HP * 4u), SV_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t hp_b = __builtin_amdgcn_make_buffer_rsrc(a.hprev, 0, R * (SV_HP * 4u), SV_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t g4_b = __builtin_amdgcn_make_buffer_rsrc(a.gates4, 0, R * (SV_HP * 16u), SV_BUF_FLAGS);
     int na = nact_s[0];
     int rbase = roff_s[0] + u0;
+#ifdef SV_GRU_TIMING
+    unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ts_last = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     for (int t = 0; t < a.Tmax; ++t) {
         if (na <= u0) break;
+        SV_TS(0)
         const unsigned short* hcur = h_bf + (t & 1) * (MB * HLDB);
         unsigned short* hnxt = h_bf + ((t + 1) & 1) * (MB * HLDB);
         // next step's scalars: fetched now, consumed after the barrier
@@ -368,83 +393,160 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
         const int na_next = (t + 1 < a.Tmax) ? nact_s[tn] : 0;
         const int rbase_next = roff_s[tn] + u0;
 
-        int rowv[4];
+        // 32-bit byte offsets of this lane's four rows (the host bounds B*Tmax so that they stay below 2^31)
+        unsigned ogi[4], ohs[4], og4[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rowv[r] = (4 * lk + r < MU && u0 + 4 * lk + r < na) ? rbase + 4 * lk + r : trash;
+        for (int r = 0; r < 4; ++r) {
+            const bool act = 4 * lk + r < MU && u0 + 4 * lk + r < na;
+            const unsigned row = rbase + 4 * lk + r;
+            ogi[r] = act ? (row * SV_G + 16 * wave + ln) * 4u : SV_BUF_OOB;
+            ohs[r] = act ? (row * SV_HP + 16 * wave + ln) * 4u : SV_BUF_OOB;
+            og4[r] = act ? (row * SV_HP + 16 * wave + ln) * 16u : SV_BUF_OOB;
+        }
 
         // input-side gates of this step: issued before the matmul so they land behind it
         float gi[NQ][4][3];
-        if (lane_on) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float* gp = a.gi + (size_t)(rowv[r] == trash ? rbase : rowv[r]) * SV_G + 16 * (wave + 4 * q) + ln;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) gi[q][r][g] = gp[g * SV_HP];
-                }
-        }
+                for (int g = 0; g < 3; ++g)
+                    gi[q][r][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gi_b, ogi[r] + (g * SV_HP + 128 * q) * 4, 0, 0));
 
         bf16x8 A[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) A[s] = *reinterpret_cast<const bf16x8*>(hcur + ln * HLDB + 32 * s + 8 * lk);
+#ifdef SV_GRU_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        SV_TS(1)
         f32x4 acc[NQ][3];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[q][g] = (f32x4){bias[q][g], bias[q][g], bias[q][g], bias[q][g]};
+        // LDS-resident fragments run through a ring of PD+1 groups (one group = the 3 gate fragments of one
+        // k-step), fetched PD groups ahead of the MFMAs that use them.  sched_barrier mask 0x676: everything
+        // but DS reads and MFMAs may cross, i.e. those two keep this source order while the gate math and
+        // the global traffic float freely.
+        constexpr int PD = 3, NGRP = NL * KS;
+        bf16x8 wb[PD + 1][3];
+#define SV_WLOAD(i_)                                                                                        \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                           \
+        wb[(i_) % (PD + 1)][g] = *reinterpret_cast<const bf16x8*>(wl + (g * KS + (i_)) * 512);
+#define SV_PIN_ORDER __builtin_amdgcn_sched_barrier(0x676);
+#pragma unroll
+        for (int i = 0; i < PD && i < NGRP; ++i) SV_WLOAD(i)
+        SV_PIN_ORDER
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], W[g][s], acc[0][g], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NGRP; ++i) {
+            SV_PIN_ORDER
+            if (i + PD < NGRP) SV_WLOAD(i + PD)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                acc[NQ - 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], wb[i % (PD + 1)][g], acc[NQ - 1][g], 0, 0, 0);
+        }
+        SV_PIN_ORDER
+#ifdef SV_GRU_TIMING
+        asm volatile("v_mov_b32 %0, %0" : "+v"(acc[NQ - 1][2][3]));
+        asm volatile("s_nop 0" ::: "memory");
+#endif
+        SV_TS(2)
+#undef SV_WLOAD
+#undef SV_PIN_ORDER
+        f32x2 s_hn[NQ][2], s_hp[NQ][2], s_rg[NQ][2], s_zg[NQ][2], s_ng[NQ][2], s_gh[NQ][2];
+#ifdef SV_GRU_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        SV_TS(3)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
+            const int j = 16 * (wave + 8 * q) + ln;
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    bf16x8 wv;
-                    if (q < NR)
-                        wv = W[q < NR ? q : 0][g][s];
-                    else
-                        wv = *reinterpret_cast<const bf16x8*>(wl + (((q - NR) * 3 + g) * KS + s) * 512);
-                    acc[q][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], wv, acc[q][g], 0, 0, 0);
-                }
-        }
-        if (lane_on) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int j = 16 * (wave + 4 * q) + ln;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float hn = gate_fwd<true>(a, (size_t)rowv[r], j, gi[q][r][0], gi[q][r][1], gi[q][r][2],
-                                                    acc[q][0][r], acc[q][1][r], acc[q][2][r], hreg[q][r]);
-                    hreg[q][r] = hn;
-                    hnxt[(4 * lk + r) * HLDB + j] = sv_f2bf(hn);
-                }
+            for (int h = 0; h < 2; ++h) {
+                const int r0 = 2 * h, r1 = 2 * h + 1;
+                const f32x2 ghr = {acc[q][0][r0], acc[q][0][r1]}, ghz = {acc[q][1][r0], acc[q][1][r1]};
+                const f32x2 ghn = {acc[q][2][r0], acc[q][2][r1]};
+                const f32x2 gir = {gi[q][r0][0], gi[q][r1][0]}, giz = {gi[q][r0][1], gi[q][r1][1]};
+                const f32x2 gin = {gi[q][r0][2], gi[q][r1][2]};
+                f32x2 er = (gir + ghr) * -1.4426950408889634f, ez = (giz + ghz) * -1.4426950408889634f;
+                er = (f32x2){__builtin_amdgcn_exp2f(er.x), __builtin_amdgcn_exp2f(er.y)} + 1.0f;
+                ez = (f32x2){__builtin_amdgcn_exp2f(ez.x), __builtin_amdgcn_exp2f(ez.y)} + 1.0f;
+                const f32x2 rg = {__builtin_amdgcn_rcpf(er.x), __builtin_amdgcn_rcpf(er.y)};
+                const f32x2 zg = {__builtin_amdgcn_rcpf(ez.x), __builtin_amdgcn_rcpf(ez.y)};
+                f32x2 en = __builtin_elementwise_fma(rg, ghn, gin) * -2.8853900817779268f;
+                en = (f32x2){__builtin_amdgcn_exp2f(en.x), __builtin_amdgcn_exp2f(en.y)} + 1.0f;
+                const f32x2 tn = {__builtin_amdgcn_rcpf(en.x), __builtin_amdgcn_rcpf(en.y)};
+                const f32x2 ng = tn * 2.0f - 1.0f;
+                const f32x2 hp = hreg[q][h];
+                const f32x2 hn = __builtin_elementwise_fma(zg, hp - ng, ng);
+                hreg[q][h] = hn;
+                s_hn[q][h] = hn; s_hp[q][h] = hp; s_rg[q][h] = rg; s_zg[q][h] = zg; s_ng[q][h] = ng; s_gh[q][h] = ghn;
+                const unsigned pk = pack_bf16(hn.x, hn.y);
+                hnxt[(4 * lk + r0) * HLDB + j] = (unsigned short)(pk & 0xffffu);
+                hnxt[(4 * lk + r1) * HLDB + j] = (unsigned short)(pk >> 16);
             }
         }
+        SV_TS(4)
+#ifndef SV_EXP_NOSTORE
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r0 = 2 * h, r1 = 2 * h + 1;
+                // (float temporaries: __builtin_bit_cast on a vector component reads component 0)
+                const float hn0 = s_hn[q][h].x, hn1 = s_hn[q][h].y, hp0 = s_hp[q][h].x, hp1 = s_hp[q][h].y;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn0), hs_b, ohs[r0] + 512 * q, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn1), hs_b, ohs[r1] + 512 * q, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hp0), hp_b, ohs[r0] + 512 * q, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hp1), hp_b, ohs[r1] + 512 * q, 0, 0);
+                const f32x4 g0 = {s_rg[q][h].x, s_zg[q][h].x, s_ng[q][h].x, s_gh[q][h].x};
+                const f32x4 g1 = {s_rg[q][h].y, s_zg[q][h].y, s_ng[q][h].y, s_gh[q][h].y};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g0), g4_b, og4[r0] + 2048 * q, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g1), g4_b, og4[r1] + 2048 * q, 0, 0);
+            }
+#endif
+        SV_TS(5)
         na = na_next;
         rbase = rbase_next;
-        __syncthreads();  // h_t published (ping-pong image: the next step writes the other buffer)
+#ifdef SV_GRU_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        SV_TS(6)
+        __syncthreads();
+        SV_TS(7)  // h_t published (ping-pong image: the next step writes the other buffer)
     }
+#ifdef SV_GRU_TIMING
+    if (blockIdx.x == 0 && wave == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) g_gru_dbg[i] = ts_acc[i];
+#endif
 }
 
-__global__ __launch_bounds__(256, 1) void gru_fwd_bf16_kernel(GruArgs a) {
+__global__ __launch_bounds__(64 * FWD_WAVES, 1) void gru_fwd_bf16_kernel(GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_f[];
     unsigned short* w_lds = smem_f;                // 6 tiles x [21][64][8]
     unsigned short* h_bf = smem_f + WLF_ELEMS;     // [2][MB][HLDB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < 2 * MB * HLDB; i += 256) h_bf[i] = 0;
+    for (int i = tid; i < 2 * MB * HLDB; i += 64 * FWD_WAVES) h_bf[i] = 0;
     __syncthreads();
-    if (wave < 2)
-        gru_fwd_bf16_body<4>(a, h_bf, w_lds, wave, lane);
+    if (wave < 6)
+        gru_fwd_bf16_body<2>(a, h_bf, w_lds, wave, lane);
     else
-        gru_fwd_bf16_body<3>(a, h_bf, w_lds, wave, lane);
+        gru_fwd_bf16_body<1>(a, h_bf, w_lds, wave, lane);
 }
 
 template <int NQ, int NR>  // hidden tiles owned by this wave / how many of them stay in registers
 __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned short* g_bf, unsigned short* w_lds,
                                                   int slot0, int wave, int lane) {
-    const int u0 = blockIdx.x * MU;
-    const bool lane_on = 4 * (lane >> 4) < MU;   // lanes whose accumulator rows are real users
+    const int u0 = blockIdx.x * MUB;
+    const bool lane_on = 4 * (lane >> 4) < MUB;   // lanes whose accumulator rows are real users
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_G / 32;  // 21 k-steps
     constexpr int NL = NQ - NR;    // tiles in LDS (fragment order, lane-linear 16-byte reads)
@@ -485,7 +587,7 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
     {                                                                                                       \
         const int na_ = nact_s[t_];                                                                         \
         const int rbase_ = roff_s[t_] + u0;                                                              \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) rowv[r] = (4 * lk + r < MU && u0 + 4 * lk + r < na_) ? rbase_ + 4 * lk + r : trash; \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) rowv[r] = (4 * lk + r < MUB && u0 + 4 * lk + r < na_) ? rbase_ + 4 * lk + r : trash; \
         if (lane_on)                                                                                        \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
@@ -588,10 +690,12 @@ extern "C" int svae_gru_fwd(const float* gi, const float* whh, const float* bhh,
         hipLaunchKernelGGL(gru_fwd_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     } else {
         grid = dim3((B + MU - 1) / MU);
+        SV_CHECK_ARG((long long)B * Tmax < (1ll << 19), "svae_gru_fwd: B*Tmax = %lld rows exceed the 32-bit addressing "
+                     "of the bf16 kernel (2^19 rows); split the batch", (long long)B * Tmax);
         const int lds = (WLF_ELEMS + 2 * MB * HLDB) * sizeof(unsigned short);   // 144 KiB of the CU's 160
         hipError_t e = hipFuncSetAttribute((const void*)gru_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_fwd: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(gru_fwd_bf16_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(gru_fwd_bf16_kernel, dim3((B + MU - 1) / MU), dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);
     }
     SV_LAUNCH_CHECK();
     return 0;
@@ -610,7 +714,7 @@ extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* g
     if (prec == 0) {
         hipLaunchKernelGGL(gru_bwd_f32_kernel, grid, dim3(256), MB * GLD * sizeof(float), (hipStream_t)stream, a);
     } else {
-        grid = dim3((B + MU - 1) / MU);
+        grid = dim3((B + MUB - 1) / MUB);
         const int lds = (WLB_ELEMS + 2 * MB * GLDB) * sizeof(unsigned short);   // 105 + 42.5 KiB
         hipError_t e = hipFuncSetAttribute((const void*)gru_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_bwd: LDS attribute: %s", hipGetErrorString(e));
@@ -619,3 +723,9 @@ extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* g
     SV_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef SV_GRU_TIMING
+extern "C" int svae_debug_gru(unsigned long long* out8) {
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gru_dbg), 8 * sizeof(unsigned long long));
+}
+#endif
