@@ -50,6 +50,12 @@ class SVAEEngine:
         self.ws = {}
         self.nsplit = 32
         self.slabs = torch.zeros(self.nsplit * (G * E + G), **f32)        # largest split-K output: dW_ih
+        self.slabs_side = torch.zeros(self.nsplit * (DP * HP + DP), **f32)  # side-stream weight gradients
+        # Backward runs on two streams: the data-gradient chain that leads to the GRU's BPTT (a 16-64 CU kernel,
+        # latency bound) stays on the caller's stream, the decoder-side weight gradients (whole-GPU kernels that
+        # nothing downstream waits for) go to a side stream and fill the CUs the recurrence leaves idle.
+        self.overlap = True
+        self._side = None
         self.colparts = torch.zeros(64 * max(self.IP, G), **f32)
         self._plan = None
         self._anneal = 0.0
@@ -105,6 +111,7 @@ class SVAEEngine:
             self.ws["ky_rows"] = torch.zeros(capp, **f32)
             self.ws["part"] = torch.zeros(8 * capp * 2, **f32)
             self.ws["pslabs"] = torch.empty(8 * max(capp, self.IPAD) * DP, **f32)
+            self.ws["pslabs_side"] = torch.empty(8 * max(capp, self.IPAD) * DP, **f32)
             if self.w3b is None:
                 self.w3b = torch.zeros(self.IPAD * DP, **bf)
                 self.w3tb = torch.zeros(DP * self.IPAD, **bf)
@@ -140,20 +147,26 @@ class SVAEEngine:
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(i)
 
-    def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx):
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx, slabs=None):
         """Weight + bias gradient of y = x W^T + b in one pass: gW[N][K] = dY[R][N]^T X[R][K] and
         gb[N] = column sums of dY (folded into the GEMM).  Split-K over rows writes one slab per split
         (weights then bias), summed in a fixed order: deterministic, no atomics.  The bias gradient sits
         right behind the weight gradient in the flat buffer (layout.py keeps them adjacent)."""
         out = self.grads[self.layout.offset(wname):]
+        slabs = self.slabs if slabs is None else slabs
         ns = max(1, min(self.nsplit, (R + 255) // 256))
         if ns == 1:
             self._gemm(dY, X, out, N, K, R, ldy, ldx, K, 1, 1, colsum=out[N * K:])
         else:
             stride = N * K + N
-            self._gemm(dY, X, self.slabs, N, K, R, ldy, ldx, K, 1, 1, nsplit=ns, slab_stride=stride,
-                       colsum=self.slabs[N * K:])
-            _lib.call("svae_reduce_slabs", self.slabs.data_ptr(), out.data_ptr(), stride, ns, stride, _stream())
+            self._gemm(dY, X, slabs, N, K, R, ldy, ldx, K, 1, 1, nsplit=ns, slab_stride=stride,
+                       colsum=slabs[N * K:])
+            _lib.call("svae_reduce_slabs", slabs.data_ptr(), out.data_ptr(), stride, ns, stride, _stream())
 
     def _colsum(self, A, out, R, N, ld):
         nparts = max(1, min(64, (R + 127) // 128))
@@ -269,26 +282,35 @@ class SVAEEngine:
         R, I, IP = plan.R, self.I, self.IP
         w, st = self.ws, _stream()
         lay = self.layout
+        side = None
         if self._last_fused:
             if plan.occ_off is None:
                 raise ValueError("fused mode needs build_plan(..., total_items=I)")
             Rp = (R + 63) // 64 * 64
-            args = (w["h2b"].data_ptr(), w["h2tb"].data_ptr(), Rp, self.w3b.data_ptr(),
-                    self.w3tb.data_ptr(), self.IPAD, w["kx_rows"].data_ptr(), w["ky_rows"].data_ptr(),
-                    self.kx_items.data_ptr(), self.ky_items.data_ptr(), w["d1"].data_ptr(),
-                    self.P("decoder.linear2.weight").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
-                    plan.occ_off.data_ptr(), plan.occ_row.data_ptr(), R, I, IP, plan.K, w["pslabs"].data_ptr(),
-                    w["dd1"].data_ptr(), self.Gv("decoder.linear2.weight").data_ptr(),
-                    self.Gv("decoder.linear2.bias").data_ptr())
-            if self.prof is None:
-                _lib.call("svae_proj_nll_bwd", *args, 15, st)
-            else:       # profiling: bracket each kernel of the call on its own
-                for bit, tag in ((1, "proj_dw_fused"), (2, "proj_dw_finish"), (4, "proj_dh_fused"),
-                                 (8, "proj_dh_finish")):
-                    ev = self._tic(tag)
-                    _lib.call("svae_proj_nll_bwd", *args, bit, st)
-                    self._toc(tag, ev)
-            self._bucket(0)
+
+            def proj_bwd(parts, slabs, tags):
+                args = (w["h2b"].data_ptr(), w["h2tb"].data_ptr(), Rp, self.w3b.data_ptr(),
+                        self.w3tb.data_ptr(), self.IPAD, w["kx_rows"].data_ptr(), w["ky_rows"].data_ptr(),
+                        self.kx_items.data_ptr(), self.ky_items.data_ptr(), w["d1"].data_ptr(),
+                        self.P("decoder.linear2.weight").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
+                        plan.occ_off.data_ptr(), plan.occ_row.data_ptr(), R, I, IP, plan.K, slabs.data_ptr(),
+                        w["dd1"].data_ptr(), self.Gv("decoder.linear2.weight").data_ptr(),
+                        self.Gv("decoder.linear2.bias").data_ptr())
+                if self.prof is None:
+                    _lib.call("svae_proj_nll_bwd", *args, parts, _stream())
+                else:       # profiling: bracket each kernel of the call on its own
+                    for bit, tag in tags:
+                        ev = self._tic(tag)
+                        _lib.call("svae_proj_nll_bwd", *args, bit, _stream())
+                        self._toc(tag, ev)
+
+            if self.overlap:
+                side = self._side_stream()
+                proj_bwd(12, w["pslabs"], ((4, "proj_dh_fused"), (8, "proj_dh_finish")))
+            else:
+                proj_bwd(15, w["pslabs"], ((1, "proj_dw_fused"), (2, "proj_dw_finish"), (4, "proj_dh_fused"),
+                                           (8, "proj_dh_finish")))
+                self._bucket(0)
         else:
             dl = w["logits"]
             self._gemm(dl, w["d1"], self.Gv("decoder.linear2.weight"), IP, DP, R, IP, DP, DP, 1, 1, tag="proj_dw")
@@ -296,21 +318,24 @@ class SVAEEngine:
             self._bucket(0)
             self._gemm(dl, self.P("decoder.linear2.weight"), w["dd1"], R, DP, IP, IP, DP, DP, 0, 1,
                        act=2, aux=w["d1"], ldaux=DP, tag="proj_dx")
-        # decoder.linear1
-        self._wgrad(w["dd1"], w["z"], "decoder.linear1.weight", R, DP, L, DP, L)
+        # data-gradient chain: decoder.linear1 -> latent -> linear1 -> encoder.linear1
         self._gemm(w["dd1"], self.P("decoder.linear1.weight"), w["dz"], R, L, DP, DP, L, L, 0, 1)
-        # latent
         _lib.call("svae_latent_bwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["dz"].data_ptr(),
                   plan.w_kl.data_ptr(), float(anneal), w["dtmp"].data_ptr(), R, st)
         if self._dtmp_extra is not None:          # dense surface: dL/dmu, dL/dlog_sigma arriving from VAELoss
             w["dtmp"][:R * 2 * L].add_(self._dtmp_extra.reshape(-1))
-        self._wgrad(w["dtmp"], w["enc"], "linear1.weight", R, 2 * L, DP, 2 * L, DP)
         self._gemm(w["dtmp"], self.P("linear1.weight"), w["denc"], R, DP, 2 * L, 2 * L, DP, DP, 0, 1,
                    act=2, aux=w["enc"], ldaux=DP)
-        # encoder.linear1
-        self._wgrad(w["denc"], w["hs"], "encoder.linear1.weight", R, DP, HP, DP, HP)
         self._gemm(w["denc"], self.P("encoder.linear1.weight"), w["dhs"], R, HP, DP, DP, HP, HP, 0, 1)
-        self._bucket(1)
+
+        def decoder_side_wgrads(slabs):
+            self._wgrad(w["dd1"], w["z"], "decoder.linear1.weight", R, DP, L, DP, L, slabs=slabs)
+            self._wgrad(w["dtmp"], w["enc"], "linear1.weight", R, 2 * L, DP, 2 * L, DP, slabs=slabs)
+            self._wgrad(w["denc"], w["hs"], "encoder.linear1.weight", R, DP, HP, DP, HP, slabs=slabs)
+            self._bucket(1)
+
+        if side is None:
+            decoder_side_wgrads(self.slabs)
         # GRU (BPTT)
         _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
         ev = self._tic("gru_bwd")
@@ -318,6 +343,14 @@ class SVAEEngine:
                   self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
                   w["dgi"].data_ptr(), w["dgh"].data_ptr(), self.gru_prec, st)
         self._toc("gru_bwd", ev)
+        if side is not None:
+            # gated on the chain above, enqueued after the recurrence so that its few workgroups get their CUs
+            # first; the weight-gradient kernels then take whatever the recurrence leaves idle
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                proj_bwd(3, w["pslabs_side"], ((1, "proj_dw_fused"), (2, "proj_dw_finish")))
+                self._bucket(0)
+                decoder_side_wgrads(self.slabs_side)
         self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
         self._wgrad(w["dgi"], w["emb"], "gru.weight_ih_l0", R, G, E, G, E)
         self._bucket(2)
@@ -328,6 +361,8 @@ class SVAEEngine:
         _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
                   plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, 1.0, st)
         self._bucket(3)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
     # ------------------------------------------------------------------ dense (notebook) surface
     def dense_loss(self, logits, mu, ls, tgt, anneal, batch_size=1.0):
