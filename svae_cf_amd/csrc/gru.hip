@@ -37,7 +37,6 @@ constexpr int MU = 4;              // bf16 kernels: users a workgroup really own
                                    // padding).  The step is bound by the CU's 64 B/clk L1<->L2 path (gi, saved
                                    // gates, dgi/dgh: >100 KB per step at 16 users), so halving the users per CU
                                    // and doubling the CUs in use shortens the recurrence's critical path.
-constexpr int MUB = 16;            // same, backward kernel
 constexpr int NJT = SV_HP / 16;    // 14 hidden-unit tiles of 16
 constexpr int HLD = SV_HP + 4;     // fp32 LDS row stride (floats) of the h image
 constexpr int GLD = SV_G + 4;      // fp32 LDS row stride (floats) of the dgh image
@@ -328,7 +327,6 @@ constexpr int WL_FRAGS = 21;                       // fragments of the LDS-resid
 // (lane-linear 16-byte reads, conflict-free): 6 tiles x 21 KiB = 126 KiB.
 constexpr int WLF_ELEMS = 6 * WL_FRAGS * 64 * 8;
 constexpr int FWD_WAVES = 8;
-constexpr int WLB_ELEMS = 5 * WL_FRAGS * 64 * 8;   // backward: 5 LDS-resident tiles (see gru_bwd_bf16_kernel)
 
 template <int NQ>  // number of hidden tiles this wave owns (2 for waves 0..5; 1 for waves 6,7)
 __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned short* h_bf, unsigned short* w_lds,
@@ -542,33 +540,39 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void gru_fwd_bf16_kernel(GruArgs
         gru_fwd_bf16_body<1>(a, h_bf, w_lds, wave, lane);
 }
 
-template <int NQ, int NR>  // hidden tiles owned by this wave / how many of them stay in registers
+// Backward: same organisation as the forward (8 waves, wave w owns hidden tiles w and w+8, the second one
+// LDS-resident; MU users per workgroup, masked lanes get out-of-range buffer offsets).  The dgh image only has
+// MU real rows: the MFMA rows of padding users alias them (row = ln % MU), their results are discarded.
+template <int NQ>
 __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned short* g_bf, unsigned short* w_lds,
-                                                  int slot0, int wave, int lane) {
-    const int u0 = blockIdx.x * MUB;
-    const bool lane_on = 4 * (lane >> 4) < MUB;   // lanes whose accumulator rows are real users
+                                                  int wave, int lane) {
+    const int u0 = blockIdx.x * MU;
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_G / 32;  // 21 k-steps
-    constexpr int NL = NQ - NR;    // tiles in LDS (fragment order, lane-linear 16-byte reads)
+    constexpr int NL = NQ - 1;
 
     // B operand of dh_{t-1} = dgh W_hh: B[k = gate column c][n = hidden j'] = W_hh[c][j'] = whh_t[j'][c]
-    bf16x8 W[NR][KS];
+    bf16x8 W[KS];
 #pragma unroll
-    for (int q = 0; q < NR; ++q)
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-            W[q][s] = load_w8(a.whh + (size_t)(16 * (wave + 4 * q) + ln) * SV_G + 32 * s + 8 * lk);
-    unsigned short* wl = w_lds + (size_t)slot0 * (WL_FRAGS * 64 * 8) + lane * 8;
-#pragma unroll
-    for (int ql = 0; ql < NL; ++ql)
+    for (int s = 0; s < KS; ++s) W[s] = load_w8(a.whh + (size_t)(16 * wave + ln) * SV_G + 32 * s + 8 * lk);
+    unsigned short* wl = w_lds + (size_t)wave * (WL_FRAGS * 64 * 8) + lane * 8;
+    if (NL > 0) {
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-            *reinterpret_cast<bf16x8*>(wl + (ql * KS + s) * 512) =
-                load_w8(a.whh + (size_t)(16 * (wave + 4 * (NR + ql)) + ln) * SV_G + 32 * s + 8 * lk);
+            *reinterpret_cast<bf16x8*>(wl + s * 512) =
+                load_w8(a.whh + (size_t)(16 * (wave + 8) + ln) * SV_G + 32 * s + 8 * lk);
+    }
 
     const sv_const_int_p nact_s = sv_scalar_ptr(a.nact), roff_s = sv_scalar_ptr(a.row_off);
     int Tw = 0;
     while (Tw < a.Tmax && nact_s[Tw] > u0) ++Tw;
+
+    const unsigned R = (unsigned)roff_s[a.Tmax];
+    const __amdgpu_buffer_rsrc_t g4_b = __builtin_amdgcn_make_buffer_rsrc(a.gates4, 0, R * (SV_HP * 16u), SV_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t hp_b = __builtin_amdgcn_make_buffer_rsrc(a.hprev, 0, R * (SV_HP * 4u), SV_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t dh_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dhs), 0, R * (SV_HP * 4u), SV_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t gi_b = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, R * (SV_G * 4u), SV_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t gh_b = __builtin_amdgcn_make_buffer_rsrc(a.dgh, 0, R * (SV_G * 4u), SV_BUF_FLAGS);
 
     float dh[NQ][4];
 #pragma unroll
@@ -576,44 +580,62 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh[q][r] = 0.f;
 
-    const int trash = roff_s[a.Tmax];
     // Saved forward values of a step are fetched one step ahead (issued right after the barrier, consumed
-    // after the matmul of the step before), so their L2 / HBM latency sits under the MFMAs and not in the
-    // recurrence's critical path.  Clamped loads; inactive users compute with d = 0 and store to the trash row.
-    float4 sg[NQ][4];
-    float shp[NQ][4], sdh[NQ][4];
-    int rowv[4];
+    // after the matmul of the step before), so their latency sits under the MFMAs.  Masked lanes read zeros
+    // (d = 0 follows) and their stores are dropped.
+    u32x4 sg[NQ][4];
+    unsigned shp[NQ][4], sdh[NQ][4];
+    unsigned ohs[4], og4[4], ogo[4];
+    bool actv[4];
 #define SV_GRU_BWD_FETCH(t_)                                                                                \
     {                                                                                                       \
         const int na_ = nact_s[t_];                                                                         \
-        const int rbase_ = roff_s[t_] + u0;                                                              \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) rowv[r] = (4 * lk + r < MUB && u0 + 4 * lk + r < na_) ? rbase_ + 4 * lk + r : trash; \
-        if (lane_on)                                                                                        \
+        const int rbase_ = roff_s[t_] + u0;                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                     \
+            actv[r] = 4 * lk + r < MU && u0 + 4 * lk + r < na_;                                             \
+            const unsigned row = rbase_ + 4 * lk + r;                                                       \
+            ohs[r] = actv[r] ? (row * SV_HP + 16 * wave + ln) * 4u : SV_BUF_OOB;                            \
+            og4[r] = actv[r] ? (row * SV_HP + 16 * wave + ln) * 16u : SV_BUF_OOB;                           \
+            ogo[r] = actv[r] ? (row * SV_G + 16 * wave + ln) * 4u : SV_BUF_OOB;                             \
+        }                                                                                                   \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
-                const size_t e = (size_t)(rowv[r] == trash ? rbase_ : rowv[r]) * SV_HP + 16 * (wave + 4 * q) + ln; \
-                sg[q][r] = *reinterpret_cast<const float4*>(a.gates4 + e * 4);                              \
-                shp[q][r] = a.hprev[e];                                                                     \
-                sdh[q][r] = a.dhs[e];                                                                       \
+                sg[q][r] = __builtin_amdgcn_raw_buffer_load_b128(g4_b, og4[r] + 2048 * q, 0, 0);            \
+                shp[q][r] = __builtin_amdgcn_raw_buffer_load_b32(hp_b, ohs[r] + 512 * q, 0, 0);             \
+                sdh[q][r] = __builtin_amdgcn_raw_buffer_load_b32(dh_b, ohs[r] + 512 * q, 0, 0);             \
             }                                                                                               \
     }
     if (Tw > 0) SV_GRU_BWD_FETCH(Tw - 1)
     for (int t = Tw - 1; t >= 0; --t) {
-        unsigned short* gcur = g_bf + (t & 1) * (MB * GLDB);
-        float carry[NQ][4] = {};
-        if (lane_on)
+        unsigned short* gcur = g_bf + (t & 1) * (MU * GLDB);
+        float carry[NQ][4];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int j = 16 * (wave + 4 * q) + ln;
+            const int j = 16 * (wave + 8 * q) + ln;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float drp, dzp, dnr;
-                const float d = (rowv[r] == trash) ? 0.f : dh[q][r] + sdh[q][r];
-                carry[q][r] = gate_bwd(a, (size_t)rowv[r], j, d, sg[q][r], shp[q][r], drp, dzp, dnr);
-                const int m = 4 * lk + r;
-                gcur[m * GLDB + j] = sv_f2bf(drp);
-                gcur[m * GLDB + SV_HP + j] = sv_f2bf(dzp);
-                gcur[m * GLDB + 2 * SV_HP + j] = sv_f2bf(dnr);
+                const float rg = __uint_as_float(sg[q][r].x), zg = __uint_as_float(sg[q][r].y);
+                const float ng = __uint_as_float(sg[q][r].z), ghn = __uint_as_float(sg[q][r].w);
+                const float d = actv[r] ? dh[q][r] + __uint_as_float(sdh[q][r]) : 0.f;
+                const float dn = d * (1.0f - zg);
+                const float dzg = d * (__uint_as_float(shp[q][r]) - ng);
+                const float dnp = dn * (1.0f - ng * ng);
+                const float dzp = dzg * zg * (1.0f - zg);
+                const float drp = dnp * ghn * rg * (1.0f - rg);
+                const float dnr = dnp * rg;
+                carry[q][r] = d * zg;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gi_b, ogo[r] + 512 * q, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gi_b, ogo[r] + 512 * q + SV_HP * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnp), gi_b, ogo[r] + 512 * q + 2 * SV_HP * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gh_b, ogo[r] + 512 * q, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gh_b, ogo[r] + 512 * q + SV_HP * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnr), gh_b, ogo[r] + 512 * q + 2 * SV_HP * 4, 0, 0);
+                if (4 * lk + r < MU) {   // compile-time for r when MU % 4 == 0: only lanes lk < MU/4 own image rows
+                    const int m = 4 * lk + r;
+                    gcur[m * GLDB + j] = sv_f2bf(drp);
+                    gcur[m * GLDB + SV_HP + j] = sv_f2bf(dzp);
+                    gcur[m * GLDB + 2 * SV_HP + j] = sv_f2bf(dnr);
+                }
             }
         }
         __syncthreads();  // dgh_t published (ping-pong: step t-1 writes the other buffer)
@@ -627,17 +649,13 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
                 bf16x8 A[7];
 #pragma unroll
                 for (int s = 0; s < 7; ++s)
-                    A[s] = *reinterpret_cast<const bf16x8*>(gcur + ln * GLDB + 32 * (s0 + s) + 8 * lk);
+                    A[s] = *reinterpret_cast<const bf16x8*>(gcur + (ln % MU) * GLDB + 32 * (s0 + s) + 8 * lk);
 #pragma unroll
                 for (int s = 0; s < 7; ++s) {
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        bf16x8 wv;
-                        if (q < NR)
-                            wv = W[q < NR ? q : 0][s0 + s];
-                        else
-                            wv = *reinterpret_cast<const bf16x8*>(wl + ((q - NR) * KS + s0 + s) * 512);
-                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], wv, acc[q], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], W[s0 + s], acc[0], 0, 0, 0);
+                    if (NQ == 2) {
+                        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wl + (s0 + s) * 512);
+                        acc[NQ - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], wv, acc[NQ - 1], 0, 0, 0);
                     }
                 }
             }
@@ -650,22 +668,16 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
 #undef SV_GRU_BWD_FETCH
 }
 
-__global__ __launch_bounds__(256, 1) void gru_bwd_bf16_kernel(GruArgs a) {
+__global__ __launch_bounds__(64 * FWD_WAVES, 1) void gru_bwd_bf16_kernel(GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_b[];
-    unsigned short* w_lds = smem_b;                // [5][21][64][8]
-    unsigned short* g_bf = smem_b + WLB_ELEMS;     // [2][MB][GLDB]
+    unsigned short* w_lds = smem_b;                // 6 tiles x [21][64][8]
+    unsigned short* g_bf = smem_b + WLF_ELEMS;     // [2][MU][GLDB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < 2 * MB * GLDB; i += 256) g_bf[i] = 0;   // padding rows stay zero
-    __syncthreads();
-    // registers vs LDS per wave: waves 0,1 own 4 tiles (2 + 2), wave 2 owns 3 (2 + 1), wave 3 owns 3 (3 + 0):
-    // the freed registers hold the one-step-ahead prefetch of the saved forward values
-    if (wave < 2)
-        gru_bwd_bf16_body<4, 2>(a, g_bf, w_lds, 2 * wave, wave, lane);
-    else if (wave == 2)
-        gru_bwd_bf16_body<3, 2>(a, g_bf, w_lds, 4, wave, lane);
+    if (wave < 6)
+        gru_bwd_bf16_body<2>(a, g_bf, w_lds, wave, lane);
     else
-        gru_bwd_bf16_body<3, 3>(a, g_bf, w_lds, 0, wave, lane);
+        gru_bwd_bf16_body<1>(a, g_bf, w_lds, wave, lane);
 }
 
 }  // namespace
@@ -714,11 +726,13 @@ extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* g
     if (prec == 0) {
         hipLaunchKernelGGL(gru_bwd_f32_kernel, grid, dim3(256), MB * GLD * sizeof(float), (hipStream_t)stream, a);
     } else {
-        grid = dim3((B + MUB - 1) / MUB);
-        const int lds = (WLB_ELEMS + 2 * MB * GLDB) * sizeof(unsigned short);   // 105 + 42.5 KiB
+        grid = dim3((B + MU - 1) / MU);
+        SV_CHECK_ARG((long long)B * Tmax < (1ll << 19), "svae_gru_bwd: B*Tmax = %lld rows exceed the 32-bit addressing "
+                     "of the bf16 kernel (2^19 rows); split the batch", (long long)B * Tmax);
+        const int lds = (WLF_ELEMS + 2 * MU * GLDB) * sizeof(unsigned short);
         hipError_t e = hipFuncSetAttribute((const void*)gru_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_bwd: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(gru_bwd_bf16_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(gru_bwd_bf16_kernel, grid, dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);
     }
     SV_LAUNCH_CHECK();
     return 0;
