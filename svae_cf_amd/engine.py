@@ -336,6 +336,9 @@ class SVAEEngine:
 
         if side is None:
             decoder_side_wgrads(self.slabs)
+        else:
+            chain_done = torch.cuda.Event()
+            chain_done.record()
         # GRU (BPTT)
         _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
         ev = self._tic("gru_bwd")
@@ -346,7 +349,7 @@ class SVAEEngine:
         if side is not None:
             # gated on the chain above, enqueued after the recurrence so that its few workgroups get their CUs
             # first; the weight-gradient kernels then take whatever the recurrence leaves idle
-            side.wait_stream(torch.cuda.current_stream())
+            side.wait_event(chain_done)
             with torch.cuda.stream(side):
                 proj_bwd(3, w["pslabs_side"], ((1, "proj_dw_fused"), (2, "proj_dw_finish")))
                 self._bucket(0)
