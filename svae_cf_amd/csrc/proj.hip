@@ -60,23 +60,28 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return *reinterpret_cast<const unsigned*>(&h);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
+// NB = 32-row x sub-tiles per wave.  NB = 2: 4 waves (one per SIMD, 512 registers each).  NB = 1: 8 waves (two per
+// SIMD): the exp / bf16-pack VALU work of one wave issues while the other wave's MFMAs execute, which a single
+// wave per SIMD only gets as far as the compiler interleaves the two statically.
+template <int MODE, int NB>
+__global__ __launch_bounds__(512 / NB, 1) void proj_kernel(ProjArgs a) {
+    constexpr int NT = 512 / NB;                 // threads
+    constexpr int NCH = (1280 + NT - 1) / NT;    // 16-byte staging chunks per thread and image
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int xt = blockIdx.x / NSPLIT, split = blockIdx.x % NSPLIT;
-    const int x0 = xt * BX + wave * 64;
+    const int x0 = xt * BX + wave * (32 * NB);
     const int ntiles = (a.ny + BY - 1) / BY;
     const int t_begin = split * a.tiles_per_split;
     int t_end = t_begin + a.tiles_per_split;
     if (t_end > ntiles) t_end = ntiles;
 
     // resident X fragments: lane (col = li -> x, half lh) element j = X[x][16 s + 8 lh + j]
-    bf16x8 xf[2][KS1];
-    float kxv[2];
+    bf16x8 xf[NB][KS1];
+    float kxv[NB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NB; ++b) {
         const int x = x0 + 32 * b + li;
         const bool ok = x < a.nx;
         kxv[b] = (MODE != MODE_FWD && ok) ? a.kx[x] : 0.f;
@@ -88,27 +93,32 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
         }
     }
 
-    f32x16 Z[2][NT2];
+    f32x16 Z[NB][NT2];
     if (MODE != MODE_FWD) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int n = 0; n < NT2; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Z[b][n][r] = 0.f;
     }
-    float run_m[2] = {NEG_BIG, NEG_BIG}, run_l[2] = {0.f, 0.f};
+    float run_m[NB], run_l[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { run_m[b] = NEG_BIG; run_l[b] = 0.f; }
 
     // ---- staging: global -> registers (issued early) -> LDS (written after the compute of the previous tile)
     // Y tile: 64 rows x 20 chunks of 16 B = 1280 chunks, 5 per thread.  Y^T tile: 160 rows x 8 chunks = 1280, 5 per thread.
+    // (scalar staging registers: arrays indexed inside guarded loops end up in scratch)
     uint4 sy0, sy1, sy2, sy3, sy4, st0, st1, st2, st3, st4;
     float skv = 0.f;
-#define SV_STAGE_LOAD1(i, SY, ST)                                                                     \
-    {                                                                                                 \
-        const int c = tid + 256 * (i);                                                                \
-        SY = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + c / 20) * KP + 8 * (c % 20));       \
-        if (MODE != MODE_FWD)                                                                         \
-            ST = *reinterpret_cast<const uint4*>(a.YT + (size_t)(c >> 3) * a.ldt + y0_ + 8 * (c & 7)); \
+#define SV_STAGE_LOAD1(i, SY, ST)                                                                         \
+    if ((i) < NCH) {                                                                                      \
+        const int c = tid + NT * (i);                                                                     \
+        if (NT * ((i) + 1) <= 1280 || c < 1280) {                                                         \
+            SY = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + c / 20) * KP + 8 * (c % 20));       \
+            if (MODE != MODE_FWD)                                                                         \
+                ST = *reinterpret_cast<const uint4*>(a.YT + (size_t)(c >> 3) * a.ldt + y0_ + 8 * (c & 7)); \
+        }                                                                                                 \
     }
 #define SV_STAGE_LOAD(t_)                                \
     {                                                    \
@@ -120,15 +130,17 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
         SV_STAGE_LOAD1(4, sy4, st4)                      \
         if (tid < BY) skv = a.ky[y0_ + tid];             \
     }
-#define SV_STAGE_STORE1(i, SY, ST)                                                                   \
-    {                                                                                                \
-        const int c = tid + 256 * (i);                                                               \
-        *reinterpret_cast<uint4*>(sY_ + (c / 20) * YLD + 8 * (c % 20)) = SY;                         \
-        if (MODE != MODE_FWD) {                                                                      \
-            uint2* d = reinterpret_cast<uint2*>(sT_ + (c >> 3) * TLD + 8 * (c & 7));                 \
-            d[0] = make_uint2(ST.x, ST.y);                                                           \
-            d[1] = make_uint2(ST.z, ST.w);                                                           \
-        }                                                                                            \
+#define SV_STAGE_STORE1(i, SY, ST)                                                                       \
+    if ((i) < NCH) {                                                                                     \
+        const int c = tid + NT * (i);                                                                    \
+        if (NT * ((i) + 1) <= 1280 || c < 1280) {                                                        \
+            *reinterpret_cast<uint4*>(sY_ + (c / 20) * YLD + 8 * (c % 20)) = SY;                         \
+            if (MODE != MODE_FWD) {                                                                      \
+                uint2* d = reinterpret_cast<uint2*>(sT_ + (c >> 3) * TLD + 8 * (c & 7));                 \
+                d[0] = make_uint2(ST.x, ST.y);                                                           \
+                d[1] = make_uint2(ST.z, ST.w);                                                           \
+            }                                                                                            \
+        }                                                                                                \
     }
 #define SV_STAGE_STORE(buf_)                                                                         \
     {                                                                                                \
@@ -161,14 +173,14 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
         // Program order per tile (2 sub-tiles of 32 y): G1(s0) G1(s1) | P(s0) G2(s0) | P(s1) G2(s1) (FWD: softmax
         // instead of P/G2): the VALU work of one sub-tile is independent of the MFMAs next to it, so the
         // scheduler can run it under them (MFMA and VALU are separate pipes).
-        f32x16 c1[2][2];
+        f32x16 c1[2][NB];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 kv = *reinterpret_cast<const float4*>(sK + sub * 32 + 8 * g + 4 * lh);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     c1[sub][b][4 * g + 0] = kv.x; c1[sub][b][4 * g + 1] = kv.y;
                     c1[sub][b][4 * g + 2] = kv.z; c1[sub][b][4 * g + 3] = kv.w;
                 }
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
             for (int s = 0; s < KS1; ++s) {
                 const bf16x8 ya = *reinterpret_cast<const bf16x8*>(sY + (sub * 32 + li) * YLD + 16 * s + 8 * lh);
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < NB; ++b)
                     c1[sub][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xf[b][s], c1[sub][b], 0, 0, 0);
             }
         }
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
         for (int sub = 0; sub < 2; ++sub) {
             if (MODE == MODE_FWD) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     float tm = c1[sub][b][0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) tm = fmaxf(tm, c1[sub][b][r]);
@@ -198,9 +210,9 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
                     run_m[b] = mn;
                 }
             } else {
-                bf16x8 pa[2][2];
+                bf16x8 pa[NB][2];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     float p[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(c1[sub][b][r], LOG2E, kxv[b]));
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
                         uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
                         const bf16x8 yb = *reinterpret_cast<bf16x8*>(&u);
 #pragma unroll
-                        for (int b = 0; b < 2; ++b)
+                        for (int b = 0; b < NB; ++b)
                             Z[b][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[b][s2], yb, Z[b][n], 0, 0, 0);
                     }
                 }
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
     if (MODE == MODE_FWD) {
         // combine the two lane halves (same x, different y) and write the split's partial (m, l)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const float om = __shfl_xor(run_m[b], 32, 64);
             const float ol = __shfl_xor(run_l[b], 32, 64);
             const float mn = fmaxf(run_m[b], om);
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
         // Z tile layout: col = li -> n, row = (r&3) + 8*(r>>2) + 4*lh -> x
         float* slab = a.out + (size_t)split * a.nx * KP;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int n = 0; n < NT2; ++n)
 #pragma unroll
@@ -261,157 +273,6 @@ __global__ __launch_bounds__(256, 1) void proj_kernel(ProjArgs a) {
                     const int x = x0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (x < a.nx) slab[(size_t)x * KP + 32 * n + li] = Z[b][n][r];
                 }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Forward, software-pipelined: the online-softmax VALU work of tile t-1 (registers only) is issued in the
-// same basic block as the MFMAs of tile t, so the two pipes overlap inside the single wave per SIMD.
-// ------------------------------------------------------------------------------------------------
-constexpr int FSTAGE_BYTES = BY * YLD * 2 + BY * 4;
-
-__device__ __forceinline__ void fwd_g1(f32x16 (&c)[2][2], const bf16x8 (&xf)[2][KS1], const unsigned short* sY,
-                                       const float* sK, int li, int lh) {
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 kv = *reinterpret_cast<const float4*>(sK + sub * 32 + 8 * g + 4 * lh);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                c[sub][b][4 * g + 0] = kv.x; c[sub][b][4 * g + 1] = kv.y;
-                c[sub][b][4 * g + 2] = kv.z; c[sub][b][4 * g + 3] = kv.w;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-            const bf16x8 ya = *reinterpret_cast<const bf16x8*>(sY + (sub * 32 + li) * YLD + 16 * s + 8 * lh);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) c[sub][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xf[b][s], c[sub][b], 0, 0, 0);
-        }
-    }
-}
-
-__device__ __forceinline__ void fwd_softmax(const f32x16 (&c)[2][2], float (&run_m)[2], float (&run_l)[2]) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        float tm = fmaxf(c[0][b][0], c[1][b][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(c[0][b][r], c[1][b][r]));
-        const float mn = fmaxf(run_m[b], tm);
-        const float mnl = mn * LOG2E;
-        float acc0 = run_l[b] * __builtin_amdgcn_exp2f((run_m[b] - mn) * LOG2E), acc1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc0 += __builtin_amdgcn_exp2f(fmaf(c[0][b][r], LOG2E, -mnl));
-            acc1 += __builtin_amdgcn_exp2f(fmaf(c[1][b][r], LOG2E, -mnl));
-        }
-        run_l[b] = acc0 + acc1;
-        run_m[b] = mn;
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void proj_fwd_kernel(ProjArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int xt = blockIdx.x / NSPLIT, split = blockIdx.x % NSPLIT;
-    const int x0 = xt * BX + wave * 64;
-    const int ntiles = (a.ny + BY - 1) / BY;
-    const int t_begin = split * a.tiles_per_split;
-    int t_end = t_begin + a.tiles_per_split;
-    if (t_end > ntiles) t_end = ntiles;
-
-    bf16x8 xf[2][KS1];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int x = x0 + 32 * b + li;
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (x < a.nx) v = *reinterpret_cast<const bf16x8*>(a.X + (size_t)x * KP + 16 * s + 8 * lh);
-            xf[b][s] = v;
-        }
-    }
-    float run_m[2] = {NEG_BIG, NEG_BIG}, run_l[2] = {0.f, 0.f};
-    uint4 sy0, sy1, sy2, sy3, sy4;
-    float skv = 0.f;
-#define SV_FLOAD(t_)                                                                                     \
-    {                                                                                                    \
-        const int y0_ = (t_) * BY;                                                                       \
-        sy0 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid) / 20) * KP + 8 * ((tid) % 20));            \
-        sy1 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid + 256) / 20) * KP + 8 * ((tid + 256) % 20)); \
-        sy2 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid + 512) / 20) * KP + 8 * ((tid + 512) % 20)); \
-        sy3 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid + 768) / 20) * KP + 8 * ((tid + 768) % 20)); \
-        sy4 = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + (tid + 1024) / 20) * KP + 8 * ((tid + 1024) % 20)); \
-        if (tid < BY) skv = a.ky[y0_ + tid];                                                             \
-    }
-#define SV_FSTORE(buf_)                                                                                  \
-    {                                                                                                    \
-        unsigned short* sY_ = reinterpret_cast<unsigned short*>(smem + (buf_) * FSTAGE_BYTES);           \
-        *reinterpret_cast<uint4*>(sY_ + ((tid) / 20) * YLD + 8 * ((tid) % 20)) = sy0;                    \
-        *reinterpret_cast<uint4*>(sY_ + ((tid + 256) / 20) * YLD + 8 * ((tid + 256) % 20)) = sy1;        \
-        *reinterpret_cast<uint4*>(sY_ + ((tid + 512) / 20) * YLD + 8 * ((tid + 512) % 20)) = sy2;        \
-        *reinterpret_cast<uint4*>(sY_ + ((tid + 768) / 20) * YLD + 8 * ((tid + 768) % 20)) = sy3;        \
-        *reinterpret_cast<uint4*>(sY_ + ((tid + 1024) / 20) * YLD + 8 * ((tid + 1024) % 20)) = sy4;      \
-        if (tid < BY) reinterpret_cast<float*>(smem + (buf_) * FSTAGE_BYTES + BY * YLD * 2)[tid] = skv;  \
-    }
-// interleave directive for one step: LDS reads up front, then every MFMA carries ~9 VALU of the softmax
-#define SV_FWD_SCHED                                                          \
-    {                                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);                   \
-        _Pragma("unroll") for (int i_ = 0; i_ < 14; ++i_) {                   \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
-            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);                \
-        }                                                                     \
-        _Pragma("unroll") for (int i_ = 0; i_ < 26; ++i_) {                   \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                \
-            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);                \
-        }                                                                     \
-    }
-#define SV_FSTEP(CN, CO, t_, SOFTMAX)                                                                    \
-    {   /* one basic block: the next tile's loads / LDS stores are unconditional (index clamped) */      \
-        const int buf_ = ((t_) - t_begin) & 1;                                                           \
-        const int tn_ = ((t_) + 1 < t_end) ? (t_) + 1 : (t_);                                            \
-        SV_FLOAD(tn_)                                                                                    \
-        fwd_g1(CN, xf, reinterpret_cast<const unsigned short*>(smem + buf_ * FSTAGE_BYTES),              \
-               reinterpret_cast<const float*>(smem + buf_ * FSTAGE_BYTES + BY * YLD * 2), li, lh);       \
-        if (SOFTMAX) {                                                                                   \
-            fwd_softmax(CO, run_m, run_l);                                                               \
-            SV_FWD_SCHED                                                                                 \
-        }                                                                                                \
-        SV_FSTORE(buf_ ^ 1)                                                                              \
-        __syncthreads();                                                                                 \
-    }
-
-    f32x16 cA[2][2], cB[2][2];
-    if (t_begin < t_end) {      // block-uniform
-        SV_FLOAD(t_begin)
-        SV_FSTORE(0)
-        __syncthreads();
-        SV_FSTEP(cA, cB, t_begin, false)        // prologue: tile t_begin -> cA, nothing to reduce yet
-        int t = t_begin + 1;
-        for (; t + 1 < t_end; t += 2) {
-            SV_FSTEP(cB, cA, t, true)           // MFMAs of tile t   -> cB, softmax of the tile held in cA
-            SV_FSTEP(cA, cB, t + 1, true)       // MFMAs of tile t+1 -> cA, softmax of tile t (cB)
-        }
-        if (t < t_end) {
-            SV_FSTEP(cB, cA, t, true)
-            fwd_softmax(cB, run_m, run_l);
-        } else {
-            fwd_softmax(cA, run_m, run_l);
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const float om = __shfl_xor(run_m[b], 32, 64);
-        const float ol = __shfl_xor(run_l[b], 32, 64);
-        const float mn = fmaxf(run_m[b], om);
-        const float l = run_l[b] * __builtin_amdgcn_exp2f((run_m[b] - mn) * LOG2E) +
-                        ol * __builtin_amdgcn_exp2f((om - mn) * LOG2E);
-        const int x = x0 + 32 * b + li;
-        if (lh == 0 && x < a.nx) reinterpret_cast<float2*>(a.out)[(size_t)split * a.nx + x] = make_float2(mn, l);
     }
 }
 
@@ -594,17 +455,19 @@ __global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __rest
     reinterpret_cast<float4*>(gw3 + (size_t)it * KP)[lane] = t;
 }
 
+constexpr int PROJ_NB = 1;   // x sub-tiles per wave of the backward kernels (see proj_kernel)
+
 template <int MODE>
 int launch_proj(const ProjArgs& a, hipStream_t st) {
     const int lds = 2 * STAGE_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)proj_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)proj_kernel<MODE, PROJ_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_proj: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     const int xt = (a.nx + BX - 1) / BX;
-    hipLaunchKernelGGL((proj_kernel<MODE>), dim3(xt * NSPLIT), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((proj_kernel<MODE, PROJ_NB>), dim3(xt * NSPLIT), dim3(512 / PROJ_NB), lds, st, a);
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -648,12 +511,7 @@ extern "C" int svae_proj_nll_fwd(const void* h2b, const void* w3b, const float* 
     ProjArgs a{(const unsigned short*)h2b, (const unsigned short*)w3b, nullptr, nullptr, ky_items, part, R, I, 0, 0};
     const int ntiles = (I + BY - 1) / BY;
     a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
-    {
-        const int lds = 2 * FSTAGE_BYTES;
-        const int xt = (a.nx + BX - 1) / BX;
-        hipLaunchKernelGGL(proj_fwd_kernel, dim3(xt * NSPLIT), dim3(256), lds, (hipStream_t)stream, a);
-        SV_LAUNCH_CHECK();
-    }
+    if (int e = launch_proj<MODE_FWD>(a, (hipStream_t)stream)) return e;
     hipLaunchKernelGGL(proj_fwd_finish_kernel, dim3((R_pad + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (const float2*)part, h2, w3, b3, tgt, w_nll, R, K, nll_row, lse, kx_rows, ky_rows, R_pad);
     SV_LAUNCH_CHECK();
