@@ -34,7 +34,8 @@ constexpr int BX = 256;            // x rows per workgroup (4 waves x 64)
 constexpr int BY = 64;             // y rows per LDS tile
 constexpr int NSPLIT = 8;
 constexpr int YLD = KP + 8;        // bf16 elements per row of the Y image (336 B)
-constexpr int TLD = BY + 4;        // bf16 elements per row of the Y^T image (136 B)
+constexpr int TLD = BY + 8;        // bf16 elements per row of the Y^T image (144 B: 16-byte aligned rows,
+                                   // 36-dword stride = conflict-free 16-byte reads over 16 rows)
 constexpr int STAGE_ELEMS = BY * YLD + KP * TLD;            // bf16 elements per stage (Y + Y^T)
 constexpr int STAGE_BYTES = STAGE_ELEMS * 2 + BY * 4;       // + ky floats
 constexpr float LOG2E = 1.4426950408889634f;
@@ -136,9 +137,10 @@ __global__ __launch_bounds__(512 / NB, 1) void proj_kernel(ProjArgs a) {
         if (NT * ((i) + 1) <= 1280 || c < 1280) {                                                        \
             *reinterpret_cast<uint4*>(sY_ + (c / 20) * YLD + 8 * (c % 20)) = SY;                         \
             if (MODE != MODE_FWD) {                                                                      \
-                uint2* d = reinterpret_cast<uint2*>(sT_ + (c >> 3) * TLD + 8 * (c & 7));                 \
+                /* y columns are stored in GEMM2's k-order: y = 16 s + 8 a + 4 h + c  ->  16 s + 8 h + 4 a + c */ \
+                uint2* d = reinterpret_cast<uint2*>(sT_ + (c >> 3) * TLD + 16 * ((c & 7) >> 1) + 4 * (c & 1)); \
                 d[0] = make_uint2(ST.x, ST.y);                                                           \
-                d[1] = make_uint2(ST.z, ST.w);                                                           \
+                d[2] = make_uint2(ST.z, ST.w);                                                           \
             }                                                                                            \
         }                                                                                                \
     }
@@ -227,16 +229,13 @@ __global__ __launch_bounds__(512 / NB, 1) void proj_kernel(ProjArgs a) {
                     }
                 }
                 // GEMM2: Z[x][n] += sum_y P[y][x] Y[y][n].  k-order of a converted accumulator: element j of
-                // half lh is y = 16 s2 + 8 (j>>2) + 4 lh + (j&3)  ->  two 8-byte reads of the Y^T image per fragment.
+                // half lh is y = 16 s2 + 8 (j>>2) + 4 lh + (j&3); the Y^T image stores its columns in that order, so a
+                // fragment is one 16-byte read.
 #pragma unroll
                 for (int n = 0; n < NT2; ++n) {
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        const unsigned short* tp = sT + (32 * n + li) * TLD + sub * 32 + 16 * s2 + 4 * lh;
-                        const uint2 lo = *reinterpret_cast<const uint2*>(tp);
-                        const uint2 hi = *reinterpret_cast<const uint2*>(tp + 8);
-                        uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        const bf16x8 yb = *reinterpret_cast<bf16x8*>(&u);
+                        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(sT + (32 * n + li) * TLD + sub * 32 + 16 * s2 + 8 * lh);
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
                             Z[b][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[b][s2], yb, Z[b][n], 0, 0, 0);
