@@ -88,7 +88,7 @@ def main():
     for _ in range(args.warmup):
         eng.train_step(plans[step % len(plans)], 0.01, seed=1234)
         step += 1
-    tags = ["proj_fwd", "proj_dw_fused", "proj_dw_finish", "proj_dh_fused", "proj_dh_finish", "proj_dw", "proj_dx",
+    tags = ["proj_fwd", "proj_fdh_fused", "proj_fdh_finish", "proj_dw_fused", "proj_dw_finish", "proj_dw", "proj_dx",
             "softmax_nll", "gru_fwd", "gru_bwd"]
     eng.prof = {t: [] for t in tags}
     barrier()
@@ -118,12 +118,12 @@ def main():
             kt[tag] = float(np.mean([a.elapsed_time(b) for a, b in evs]))     # ms
     eng.prof = None
     rows_step = rows_done / args.steps
-    # Algorithmic work per launch: one projection-sized contraction = 300*I flop per row; the
-    # fused forward kernel does one, each fused backward kernel two (logit recompute + gradient GEMM); the
-    # GRU recurrence 2*200*600 flop per row (forward) and twice that in backward (dgh W_hh only: same count).
+    # Algorithmic work per launch: one projection-sized contraction = 300*I flop per row; each
+    # fused kernel does two (forward+dL/dh sweep: logits and P W3; weight-gradient sweep: logit recompute and
+    # P^T h); the GRU recurrence 2*200*600 flop per row (forward), the same count in backward (dgh W_hh).
     proj_flop = 300.0 * I * rows_step
     work = {
-        "proj_fwd": ("mfma", proj_flop), "proj_dh_fused": ("mfma", 2 * proj_flop),
+        "proj_fwd": ("mfma", proj_flop), "proj_fdh_fused": ("mfma", 2 * proj_flop),
         "proj_dw_fused": ("mfma", 2 * proj_flop), "proj_dw": ("mfma", proj_flop), "proj_dx": ("mfma", proj_flop),
         "gru_fwd": ("mfma", 240000.0 * rows_step), "gru_bwd": ("mfma", 240000.0 * rows_step),
         "softmax_nll": ("hbm", rows_step * I * 4 * 2 + rows_step * 4 * 4),

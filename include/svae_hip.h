@@ -85,24 +85,33 @@ int svae_loss_reduce(const float* nll_row, const float* kl_row, const float* w_n
                      int R, float* out3, void* stream);
 
 /* ---- fused projection + log-softmax + NLL (bf16 MFMA path; logits are never materialised) -----------
- * Replace Decoder.linear2 nb:710 + F.log_softmax nb:802 + likelihood nb:805-808 and their autograd.
- * svae_proj_prep makes the bf16 operand copies (dst [n_pad][160], dstT [160][ldt]; ones_col >= 0 sets
- * that column to 1.0); svae_proj_bias_consts the per-item constants.  See csrc/proj.hip.
- * svae_proj_nll_bwd parts (bit mask, 15 = everything): 1 weight-gradient kernel, 2 its finish (sparse target
- * part, writes gw3/gb3), 4 hidden-gradient kernel, 8 its finish (writes dd1); pieces share `slabs` and must
- * be enqueued in that order -- the split exists so a profiler can bracket one kernel. */
+ * Replace Decoder.linear2 nb:710 + F.log_softmax nb:802 + likelihood nb:805-808 and their autograd
+ * (loss.backward() nb:1205).  See csrc/proj.hip for the operand copies and their constant columns.
+ *   svae_proj_prep_rows   bf16 copies of the decoder hidden rows h2 [R][160] (tanh of Decoder.linear1 nb:709):
+ *                         h2b plain, h2s scaled by log2(e) (both [R_pad][160]), h2tb transposed [160][R_pad]
+ *   svae_proj_prep_items  the same for Decoder.linear2's weight w3 [I][160] and bias b3: w3b, w3s, w3tb
+ *   svae_proj_nll_fwd     loss only (scoring): nll_row[R], lse[R];  part = 16 R floats of scratch
+ *   svae_proj_nll_fwd_dh  forward AND the hidden-side gradient in one sweep over the items: nll_row, lse,
+ *                         dd1 [R][160] = dL/d(pre-tanh decoder hidden); writes the row constants into h2b.
+ *                         slabs = 8 R 160 floats, mpart = 8 R floats of scratch
+ *   svae_proj_nll_bwd_dw  weight-side gradient gw3 [I_rows][160], gb3 [I_rows] (after _fwd_dh of the same
+ *                         batch); slabs = 8 I 160 floats; occ_off [I+1] / occ_row = target occurrences by item
+ * R_pad, I_pad: multiples of 64.  parts (bit mask, 3 = everything): 1 sweep kernel, 2 finish kernel -- the
+ * split exists so a profiler can bracket one kernel. */
 int svae_proj_nsplit(void);
 int svae_proj_tile(void);
-int svae_proj_prep(const float* src, void* dst, void* dstT, int n, int n_pad, int ldt, int ones_col, void* stream);
-int svae_proj_bias_consts(const float* b3, float* ky_items, float* kx_items, int I, int I_pad, void* stream);
-int svae_proj_nll_fwd(const void* h2b, const void* w3b, const float* ky_items, const float* h2, const float* w3,
-                      const float* b3, const int* tgt, const float* w_nll, int R, int R_pad, int I, int K,
-                      float* part, float* nll_row, float* lse, float* kx_rows, float* ky_rows, void* stream);
-int svae_proj_nll_bwd(const void* h2b, const void* h2tb, int ldt_rows, const void* w3b, const void* w3tb,
-                      int ldt_items, const float* kx_rows, const float* ky_rows, const float* kx_items,
-                      const float* ky_items, const float* h2, const float* w3, const int* tgt, const float* w_nll,
-                      const int* occ_off, const int* occ_row, int R, int I, int I_pad, int K, float* slabs,
-                      float* dd1, float* gw3, float* gb3, int parts, void* stream);
+int svae_proj_prep_rows(const float* h2, int R, int R_pad, void* h2b, void* h2s, void* h2tb, void* stream);
+int svae_proj_prep_items(const float* w3, const float* b3, int I, int I_pad, void* w3b, void* w3s, void* w3tb,
+                         void* stream);
+int svae_proj_nll_fwd(const void* h2s, const void* w3b, const float* h2, const float* w3, const float* b3,
+                      const int* tgt, int R, int I, int K, float* part, float* nll_row, float* lse, void* stream);
+int svae_proj_nll_fwd_dh(const void* h2s, void* h2b, const void* w3b, const void* w3tb, int I_pad, const float* h2,
+                         const float* w3, const float* b3, const int* tgt, const float* w_nll, int R, int I, int K,
+                         float* slabs, float* mpart, float* nll_row, float* lse, float* dd1, int parts,
+                         void* stream);
+int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad, int I, int I_rows,
+                         const float* h2, const float* w_nll, const int* occ_off, const int* occ_row, float* slabs,
+                         float* gw3, float* gb3, int parts, void* stream);
 
 /* ---- Adam with L2 weight decay on one flat buffer ----------------------------------------------------
  * Replaces optimizer.step() nb:1206 with torch.optim.Adam(weight_decay=5e-3) nb:1260-1263 (and the

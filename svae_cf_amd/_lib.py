@@ -35,11 +35,11 @@ SIGNATURES = {
     "svae_gather_rows": [_P, _P, _P, _I, _I, _I, _I, _P],
     "svae_masked_topk": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "svae_philox_normal": [_P, _P, _I, _ULL, _U, _P],
-    "svae_proj_prep": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "svae_proj_bias_consts": [_P, _P, _P, _I, _I, _P],
-    "svae_proj_nll_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "svae_proj_nll_bwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
-                          _P, _P, _P, _P, _I, _P],
+    "svae_proj_prep_rows": [_P, _I, _I, _P, _P, _P, _P],
+    "svae_proj_prep_items": [_P, _P, _I, _I, _P, _P, _P, _P],
+    "svae_proj_nll_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "svae_proj_nll_fwd_dh": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    "svae_proj_nll_bwd_dw": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "svae_proj_nsplit": [],
     "svae_proj_tile": [],
     "svae_check_device": [],

@@ -2,23 +2,43 @@
 // WITHOUT materialising the [rows x items] logits (reference: Decoder.linear2 nb:710, F.log_softmax
 // nb:802, likelihood nb:805-808, and their autograd).
 //
-// One kernel template, three modes.  An "X" operand is resident (64 rows of it per wave as MFMA B
-// fragments in registers), a "Y" operand streams through LDS in tiles of 64 rows:
+// One kernel template, three modes.  An "X" operand is resident (32 rows of it per wave as MFMA B
+// fragments in registers), a "Y" operand streams through LDS in tiles of 64 rows, written there by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass):
 //
 //   GEMM1   C1[y][x] = sum_k Y[y][k] X[x][k]           v_mfma_f32_32x32x16_bf16, K = 160 (10 steps)
-//           accumulator initialised with a per-y constant ky[y]  (bias, or ln c_r - lse_r)
-//   FWD     X = decoder hidden rows h2[r], Y = W3[i]:  per-lane online (max, sum-exp) over y -- the
-//           logit's data row sits on the lane (swapped orientation), so no cross-lane reduction.
-//   DH      X = h2[r], Y = W3[i]:  P = exp2(C1*log2e + kx[x]) = c_r softmax;  GEMM2  Z[x][n] += P^T Y
-//           -> dL/dh2 (dense part)
-//   DW      X = W3[i], Y = h2[r]:  P as above with the roles of kx / ky swapped;  GEMM2 Z[x][n] += P^T Y
-//           -> dL/dW3 (dense part); column 150 of h2's bf16 copy is 1.0, so Z[:,150] = dL/db3.
-//   GEMM2 contracts over y, the REGISTER index of C1: the accumulator tile is converted to bf16 in
-//   place and used directly as the A operand (no LDS round trip); its B operand comes from a
-//   transposed bf16 copy of Y staged next to the tile.
+//           P[y][x]  = exp2(C1[y][x])                  -- nothing else: see "constant columns"
+//   GEMM2   Z[x][n] += sum_y P[y][x] Y[y][n]           contraction over y = the REGISTER index of C1: the
+//           accumulator tile is converted to bf16 in place and fed back as the A operand (no LDS round
+//           trip); its B operand is a transposed bf16 copy of Y staged beside the tile.
 //
-// The sparse "-y" part of dlogits = w (n softmax - y) is applied by the slab-reduce epilogues
-// (targets are <= k per row; see proj_dh_finish / proj_dw_finish).
+//   FDH     X = decoder hidden rows h2[r], Y = W3[i].  Forward AND hidden gradient in ONE sweep over the
+//           items (flash-attention style): P = exp2(logit2 - m_r) with a running stabiliser m_r,
+//           Z[r][0:150] = sum_i P W3[i] (un-normalised dL/dh2), Z[r][155] = sum_i P (softmax denominator).
+//           The finish kernel normalises: lse, NLL, dL/dh2 = (c_r / l_r) Z - (target part), tanh'.
+//   FWD     the same sweep without GEMM2 (loss only: scoring).
+//   DW      X = W3[i], Y = h2[r]:  P = c_r softmax (lse known by now);  Z[i][0:150] = dL/dW3 (dense part),
+//           Z[i][150] = dL/db3 (h2's bf16 copy has a ones column).
+//
+// Constant columns.  K is padded 150 -> 160; the pad columns carry every additive constant of the
+// exponent through the MFMA itself, so the VALU work per logit is one v_exp_f32 and half a
+// v_cvt_pk_bf16_f32.  All GEMM1 exponents are in log2 units: the resident operand is a copy scaled by
+// log2(e) (h2s, w3s); constants are split into bf16 hi + lo parts (16 significant bits).
+//
+//   column            150   151/152            153/154              155/156
+//   h2b  (Y of DW)    1     1 / 1              (log2 c_r - lse2_r)  0
+//   h2s  (X of FDH)   0     1 / 1              0                    (-m_r, kept in REGISTERS only)
+//   w3b  (Y of FDH)   0     log2e*b_i hi/lo    0                    1 / 1
+//   w3s  (X of DW)    0     log2e*b_i hi/lo    1 / 1                0
+//   pad rows of h2b carry -1e30 in column 153, pad items of w3b -1e30 in column 151: P = 0 there.
+//
+// The running stabiliser (FDH / FWD): m_r starts at the first sub-tile's maximum and is raised lazily,
+// only when a logit exceeds it by more than 2^16 (a wave-uniform, almost never taken branch): the lane
+// that owns row r rewrites its own X fragment (columns 155/156) and rescales Z.  Splits use their own m;
+// the finish kernel combines them.
+//
+// The sparse "-y" part of dlogits = w (n softmax - y) is applied by the finish kernels (targets are
+// <= k per row).
 //
 // Grid: 1-D, id -> (x tile = id / 8, y split = id % 8): blocks that share an XCD (id % 8) stream
 // the same eighth of Y, which then stays in that XCD's L2.  Each split writes its own fp32 slab
@@ -30,26 +50,33 @@ namespace {
 constexpr int KP = SV_DP;          // 160
 constexpr int KS1 = KP / 16;       // 10 k-steps of GEMM1
 constexpr int NT2 = KP / 32;       // 5 n-tiles of GEMM2
-constexpr int BX = 256;            // x rows per workgroup (4 waves x 64)
+constexpr int BX = 256;            // x rows per workgroup
 constexpr int BY = 64;             // y rows per LDS tile
 constexpr int NSPLIT = 8;
-constexpr int YLD = KP + 8;        // bf16 elements per row of the Y image (336 B)
-constexpr int TLD = BY + 8;        // bf16 elements per row of the Y^T image (144 B: 16-byte aligned rows,
-                                   // 36-dword stride = conflict-free 16-byte reads over 16 rows)
-constexpr int STAGE_ELEMS = BY * YLD + KP * TLD;            // bf16 elements per stage (Y + Y^T)
-constexpr int STAGE_BYTES = STAGE_ELEMS * 2 + BY * 4;       // + ky floats
+constexpr int C_ONE = 150, C_BH = 151, C_BL = 152, C_RH = 153, C_RL = 154, C_MH = 155, C_ML = 156;
+// LDS images of one stage, both UNPADDED and XOR-swizzled in units of 16-byte chunks (the swizzle is
+// applied to the LDS-DMA's per-lane SOURCE address; the destination is lane-linear):
+//   Y   [64 rows][20 chunks]   chunk c of row r at position c ^ ((r >> 2) & 3)
+//   Y^T [160 rows][8 chunks]   chunk c of row n at position c ^ ((n >> 1) & 7)
+// -> every ds_read_b128 of a fragment is conflict-free (16 lanes of a read group hit 16 distinct bank quads).
+constexpr int YIMG_BYTES = BY * KP * 2;        // 20480
+constexpr int TIMG_BYTES = KP * BY * 2;        // 20480
+constexpr int STAGE_BYTES = YIMG_BYTES + TIMG_BYTES;
+constexpr int NCHUNK = YIMG_BYTES / 16;        // 1280 chunks per image
+constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * 32 * 4;   // + per-wave rescale factors
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_THR = 16.0f;           // log2 units
 
-enum { MODE_FWD = 0, MODE_DH = 1, MODE_DW = 2 };
+enum { MODE_FWD = 0, MODE_FDH = 1, MODE_DW = 2 };
 
 struct ProjArgs {
-    const unsigned short* X;    // [nx][160] bf16
-    const unsigned short* Y;    // [ny_pad][160] bf16 (rows >= ny are zero)
-    const unsigned short* YT;   // [160][ldt] bf16 (transposed copy of Y; columns >= ny zero)
-    const float* kx;            // [nx]      per-x exponent constant (log2 units); unused in FWD
-    const float* ky;            // [ny_pad]  per-y accumulator initial value (natural units; pads = -1e30)
-    float* out;                 // FWD: float2 partial (m, l) [NSPLIT][nx];  DH/DW: slabs [NSPLIT][nx][160]
+    const unsigned short* X;    // [nx][160] bf16, scaled copy (h2s / w3s)
+    const unsigned short* Y;    // [ny_pad][160] bf16 (h2b / w3b)
+    const unsigned short* YT;   // [160][ldt] bf16: transposed copy of Y, columns in GEMM2's k-order
+    float* out;                 // FWD: float2 (m, l) [NSPLIT][nx];  FDH / DW: slabs [NSPLIT][nx][160]
+    float* mpart;               // FDH: [NSPLIT][nx] stabiliser of each split
     int nx, ny, ldt;
     int tiles_per_split;
 };
@@ -61,281 +88,274 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return *reinterpret_cast<const unsigned*>(&h);
 }
 
-// NB = 32-row x sub-tiles per wave.  NB = 2: 4 waves (one per SIMD, 512 registers each).  NB = 1: 8 waves (two per
-// SIMD): the exp / bf16-pack VALU work of one wave issues while the other wave's MFMAs execute, which a single
-// wave per SIMD only gets as far as the compiler interleaves the two statically.
-template <int MODE, int NB>
-__global__ __launch_bounds__(512 / NB, 1) void proj_kernel(ProjArgs a) {
-    constexpr int NT = 512 / NB;                 // threads
-    constexpr int NCH = (1280 + NT - 1) / NT;    // 16-byte staging chunks per thread and image
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// 8 waves, two per SIMD: the exp / bf16-pack VALU work of one wave issues while the partner's MFMAs execute.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int xt = blockIdx.x / NSPLIT, split = blockIdx.x % NSPLIT;
-    const int x0 = xt * BX + wave * (32 * NB);
+    const int x0 = xt * BX + wave * 32;
     const int ntiles = (a.ny + BY - 1) / BY;
     const int t_begin = split * a.tiles_per_split;
     int t_end = t_begin + a.tiles_per_split;
     if (t_end > ntiles) t_end = ntiles;
 
     // resident X fragments: lane (col = li -> x, half lh) element j = X[x][16 s + 8 lh + j]
-    bf16x8 xf[NB][KS1];
-    float kxv[NB];
+    const int x = x0 + li;
+    const bool xok = x < a.nx;
+    bf16x8 xf[KS1];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int x = x0 + 32 * b + li;
-        const bool ok = x < a.nx;
-        kxv[b] = (MODE != MODE_FWD && ok) ? a.kx[x] : 0.f;
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) v = *reinterpret_cast<const bf16x8*>(a.X + (size_t)x * KP + 16 * s + 8 * lh);
-            xf[b][s] = v;
-        }
+    for (int s = 0; s < KS1; ++s) {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (xok) v = *reinterpret_cast<const bf16x8*>(a.X + (size_t)x * KP + 16 * s + 8 * lh);
+        xf[s] = v;
     }
 
-    f32x16 Z[NB][NT2];
+    f32x16 Z[NT2];
     if (MODE != MODE_FWD) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int n = 0; n < NT2; ++n)
 #pragma unroll
-            for (int n = 0; n < NT2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Z[b][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) Z[n][r] = 0.f;
     }
-    float run_m[NB], run_l[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) { run_m[b] = NEG_BIG; run_l[b] = 0.f; }
+    float m_eff = 0.f, l_run = 0.f;
+    float thr = -3.0e38f;      // the first sub-tile always sets the stabiliser
 
-    // ---- staging: global -> registers (issued early) -> LDS (written after the compute of the previous tile)
-    // Y tile: 64 rows x 20 chunks of 16 B = 1280 chunks, 5 per thread.  Y^T tile: 160 rows x 8 chunks = 1280, 5 per thread.
-    // (scalar staging registers: arrays indexed inside guarded loops end up in scratch)
-    uint4 sy0, sy1, sy2, sy3, sy4, st0, st1, st2, st3, st4;
-    float skv = 0.f;
-#define SV_STAGE_LOAD1(i, SY, ST)                                                                         \
-    if ((i) < NCH) {                                                                                      \
-        const int c = tid + NT * (i);                                                                     \
-        if (NT * ((i) + 1) <= 1280 || c < 1280) {                                                         \
-            SY = *reinterpret_cast<const uint4*>(a.Y + (size_t)(y0_ + c / 20) * KP + 8 * (c % 20));       \
-            if (MODE != MODE_FWD)                                                                         \
-                ST = *reinterpret_cast<const uint4*>(a.YT + (size_t)(c >> 3) * a.ldt + y0_ + 8 * (c & 7)); \
-        }                                                                                                 \
+    // ---- LDS-DMA staging: chunk p = tid + 512 i of an image lands at byte 16 p; its source is swizzled
+    unsigned offY[3], offT[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = tid + 512 * i;
+        const int row = p / 20, cs = p % 20;
+        offY[i] = (unsigned)(row * (KP * 2) + 16 * (cs ^ ((row >> 2) & 3)));
+        const int n = p >> 3, ct = p & 7;
+        offT[i] = (unsigned)(n * a.ldt * 2 + 16 * (ct ^ ((n >> 1) & 7)));
     }
-#define SV_STAGE_LOAD(t_)                                \
-    {                                                    \
-        const int y0_ = (t_) * BY;                       \
-        SV_STAGE_LOAD1(0, sy0, st0)                      \
-        SV_STAGE_LOAD1(1, sy1, st1)                      \
-        SV_STAGE_LOAD1(2, sy2, st2)                      \
-        SV_STAGE_LOAD1(3, sy3, st3)                      \
-        SV_STAGE_LOAD1(4, sy4, st4)                      \
-        if (tid < BY) skv = a.ky[y0_ + tid];             \
-    }
-#define SV_STAGE_STORE1(i, SY, ST)                                                                       \
-    if ((i) < NCH) {                                                                                     \
-        const int c = tid + NT * (i);                                                                    \
-        if (NT * ((i) + 1) <= 1280 || c < 1280) {                                                        \
-            *reinterpret_cast<uint4*>(sY_ + (c / 20) * YLD + 8 * (c % 20)) = SY;                         \
-            if (MODE != MODE_FWD) {                                                                      \
-                /* y columns are stored in GEMM2's k-order: y = 16 s + 8 a + 4 h + c  ->  16 s + 8 h + 4 a + c */ \
-                uint2* d = reinterpret_cast<uint2*>(sT_ + (c >> 3) * TLD + 16 * ((c & 7) >> 1) + 4 * (c & 1)); \
-                d[0] = make_uint2(ST.x, ST.y);                                                           \
-                d[2] = make_uint2(ST.z, ST.w);                                                           \
-            }                                                                                            \
-        }                                                                                                \
-    }
-#define SV_STAGE_STORE(buf_)                                                                         \
-    {                                                                                                \
-        unsigned short* sY_ = reinterpret_cast<unsigned short*>(smem + (buf_) * STAGE_BYTES);        \
-        unsigned short* sT_ = sY_ + BY * YLD;                                                        \
-        float* sK_ = reinterpret_cast<float*>(smem + (buf_) * STAGE_BYTES + STAGE_ELEMS * 2);        \
-        SV_STAGE_STORE1(0, sy0, st0)                                                                 \
-        SV_STAGE_STORE1(1, sy1, st1)                                                                 \
-        SV_STAGE_STORE1(2, sy2, st2)                                                                 \
-        SV_STAGE_STORE1(3, sy3, st3)                                                                 \
-        SV_STAGE_STORE1(4, sy4, st4)                                                                 \
-        if (tid < BY) sK_[tid] = skv;                                                                \
+    const char* Yg = reinterpret_cast<const char*>(a.Y);
+    const char* Tg = reinterpret_cast<const char*>(a.YT);
+#define SV_STAGE(t_, buf_)                                                                       \
+    {                                                                                            \
+        const char* yb_ = Yg + (size_t)(t_) * (BY * KP * 2);                                     \
+        const char* tb_ = Tg + (size_t)(t_) * (BY * 2);                                          \
+        char* ly_ = smem + (buf_) * STAGE_BYTES + wave * 1024;                                   \
+        glds16(yb_ + offY[0], ly_);                                                              \
+        glds16(yb_ + offY[1], ly_ + 8192);                                                       \
+        if (wave < 4) glds16(yb_ + offY[2], ly_ + 16384);                                        \
+        if (MODE != MODE_FWD) {                                                                  \
+            glds16(tb_ + offT[0], ly_ + YIMG_BYTES);                                             \
+            glds16(tb_ + offT[1], ly_ + YIMG_BYTES + 8192);                                      \
+            if (wave < 4) glds16(tb_ + offT[2], ly_ + YIMG_BYTES + 16384);                       \
+        }                                                                                        \
     }
 
-    if (t_begin < t_end) {
-        SV_STAGE_LOAD(t_begin)
-        SV_STAGE_STORE(0)
-    }
+    // fragment read offsets inside a stage
+    const int sw = (li >> 2) & 3, sw2 = (li >> 1) & 7;
+    const int ra0 = li * (KP * 2) + 16 * (lh ^ sw), ra1 = li * (KP * 2) + 16 * ((2 + lh) ^ sw);
+    int rb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[q] = YIMG_BYTES + li * (BY * 2) + 16 * ((2 * q + lh) ^ sw2);
+    float* fs = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES) + wave * 32;
+
+    if (t_begin < t_end) SV_STAGE(t_begin, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
-        const bool more = (t + 1) < t_end;
-        if (more) SV_STAGE_LOAD(t + 1)
-        const unsigned short* sY = reinterpret_cast<const unsigned short*>(smem + buf * STAGE_BYTES);
-        const unsigned short* sT = sY + BY * YLD;
-        const float* sK = reinterpret_cast<const float*>(smem + buf * STAGE_BYTES + STAGE_ELEMS * 2);
+        if (t + 1 < t_end) SV_STAGE(t + 1, buf ^ 1)
+        const char* st = smem + buf * STAGE_BYTES;
 
-        // accumulator rows of a 32x32 tile: y = (r&3) + 8*(r>>2) + 4*lh  -> groups of 4 consecutive y.
-        // Program order per tile (2 sub-tiles of 32 y): G1(s0) G1(s1) | P(s0) G2(s0) | P(s1) G2(s1) (FWD: softmax
-        // instead of P/G2): the VALU work of one sub-tile is independent of the MFMAs next to it, so the
-        // scheduler can run it under them (MFMA and VALU are separate pipes).
-        f32x16 c1[2][NB];
+        // accumulator rows of a 32x32 tile: y = (r&3) + 8*(r>>2) + 4*lh  -> groups of 4 consecutive y
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            f32x16 c1;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 kv = *reinterpret_cast<const float4*>(sK + sub * 32 + 8 * g + 4 * lh);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    c1[sub][b][4 * g + 0] = kv.x; c1[sub][b][4 * g + 1] = kv.y;
-                    c1[sub][b][4 * g + 2] = kv.z; c1[sub][b][4 * g + 3] = kv.w;
-                }
-            }
+            for (int r = 0; r < 16; ++r) c1[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < KS1; ++s) {
-                const bf16x8 ya = *reinterpret_cast<const bf16x8*>(sY + (sub * 32 + li) * YLD + 16 * s + 8 * lh);
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-                    c1[sub][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xf[b][s], c1[sub][b], 0, 0, 0);
+                const bf16x8 ya = *reinterpret_cast<const bf16x8*>(st + sub * (32 * KP * 2) + 64 * (s >> 1) + ((s & 1) ? ra1 : ra0));
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xf[s], c1, 0, 0, 0);
             }
-        }
+            if (MODE != MODE_DW) {
+                float tm = fmaxf(c1[0], c1[1]);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            if (MODE == MODE_FWD) {
+                for (int r = 2; r < 16; r += 2) tm = fmaxf(tm, fmaxf(c1[r], c1[r + 1]));
+                tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+                const bool need = tm > thr;
+                if (__any(need)) {
+                    // raise the stabiliser of the rows that need it; the value used is the one the bf16 hi/lo pair
+                    // represents exactly, so the MFMA and the bookkeeping agree
+                    const float mn = fmaxf(m_eff + tm, -1.0e4f);
+                    const unsigned short hi = sv_f2bf(-mn);
+                    const float hif = sv_bf2f(hi);
+                    const unsigned short lo = sv_f2bf(-mn - hif);
+                    const float mq = need ? -(hif + sv_bf2f(lo)) : m_eff;
+                    const float delta = m_eff - mq;          // <= 0 (0 for rows left alone)
+                    const float f = __builtin_amdgcn_exp2f(delta);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    float tm = c1[sub][b][0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, c1[sub][b][r]);
-                    const float mn = fmaxf(run_m[b], tm);
-                    const float mnl = mn * LOG2E;
-                    float acc = run_l[b] * __builtin_amdgcn_exp2f((run_m[b] - mn) * LOG2E);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc += __builtin_amdgcn_exp2f(fmaf(c1[sub][b][r], LOG2E, -mnl));
-                    run_l[b] = acc;
-                    run_m[b] = mn;
-                }
-            } else {
-                bf16x8 pa[NB][2];
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    float p[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(c1[sub][b][r], LOG2E, kxv[b]));
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        uint4 u;
-                        u.x = pack_bf16(p[8 * s2 + 0], p[8 * s2 + 1]);
-                        u.y = pack_bf16(p[8 * s2 + 2], p[8 * s2 + 3]);
-                        u.z = pack_bf16(p[8 * s2 + 4], p[8 * s2 + 5]);
-                        u.w = pack_bf16(p[8 * s2 + 6], p[8 * s2 + 7]);
-                        pa[b][s2] = *reinterpret_cast<bf16x8*>(&u);
+                    for (int r = 0; r < 16; ++r) c1[r] += delta;
+                    if (need && lh == 1) {
+                        xf[KS1 - 1][C_MH - 152] = (short)hi;
+                        xf[KS1 - 1][C_ML - 152] = (short)lo;
                     }
+                    m_eff = mq;
+                    if (MODE == MODE_FWD) {
+                        l_run *= f;
+                    } else {
+                        // Z rows are x = (r&3) + 8 (r>>2) + 4 lh: fetch the factors of those rows through LDS
+                        if (lh == 0) fs[li] = f;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 fv = *reinterpret_cast<const float4*>(fs + 8 * g + 4 * lh);
+#pragma unroll
+                            for (int n = 0; n < NT2; ++n) {
+                                Z[n][4 * g + 0] *= fv.x; Z[n][4 * g + 1] *= fv.y;
+                                Z[n][4 * g + 2] *= fv.z; Z[n][4 * g + 3] *= fv.w;
+                            }
+                        }
+                    }
+                    thr = RESCALE_THR;
+                }
+            }
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(c1[r]);
+            if (MODE == MODE_FWD) {
+                float acc = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc += p[r];
+                l_run += acc;
+            } else {
+                bf16x8 pa[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    uint4 u;
+                    u.x = pack_bf16(p[8 * s2 + 0], p[8 * s2 + 1]);
+                    u.y = pack_bf16(p[8 * s2 + 2], p[8 * s2 + 3]);
+                    u.z = pack_bf16(p[8 * s2 + 4], p[8 * s2 + 5]);
+                    u.w = pack_bf16(p[8 * s2 + 6], p[8 * s2 + 7]);
+                    pa[s2] = *reinterpret_cast<bf16x8*>(&u);
                 }
                 // GEMM2: Z[x][n] += sum_y P[y][x] Y[y][n].  k-order of a converted accumulator: element j of
-                // half lh is y = 16 s2 + 8 (j>>2) + 4 lh + (j&3); the Y^T image stores its columns in that order, so a
-                // fragment is one 16-byte read.
+                // half lh is y = 16 s2 + 8 (j>>2) + 4 lh + (j&3); the Y^T copy stores its columns in that order
+                // (proj_prep), so a fragment is one 16-byte read.
 #pragma unroll
                 for (int n = 0; n < NT2; ++n) {
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(sT + (32 * n + li) * TLD + sub * 32 + 16 * s2 + 8 * lh);
-#pragma unroll
-                        for (int b = 0; b < NB; ++b)
-                            Z[b][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[b][s2], yb, Z[b][n], 0, 0, 0);
+                        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(st + n * (32 * BY * 2) + rb[2 * sub + s2]);
+                        Z[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2], yb, Z[n], 0, 0, 0);
                     }
                 }
             }
         }
-        if (more) SV_STAGE_STORE(buf ^ 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+#undef SV_STAGE
 
+    const bool any_tile = t_begin < t_end;
     if (MODE == MODE_FWD) {
-        // combine the two lane halves (same x, different y) and write the split's partial (m, l)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float om = __shfl_xor(run_m[b], 32, 64);
-            const float ol = __shfl_xor(run_l[b], 32, 64);
-            const float mn = fmaxf(run_m[b], om);
-            const float l = run_l[b] * __builtin_amdgcn_exp2f((run_m[b] - mn) * LOG2E) +
-                            ol * __builtin_amdgcn_exp2f((om - mn) * LOG2E);
-            const int x = x0 + 32 * b + li;
-            if (lh == 0 && x < a.nx)
-                reinterpret_cast<float2*>(a.out)[(size_t)split * a.nx + x] = make_float2(mn, l);
-        }
+        // the two lane halves hold the same x (and the same m), different y
+        const float l = l_run + __shfl_xor(l_run, 32, 64);
+        if (lh == 0 && xok)
+            reinterpret_cast<float2*>(a.out)[(size_t)split * a.nx + x] = make_float2(any_tile ? m_eff : NEG_BIG, l);
     } else {
         // Z tile layout: col = li -> n, row = (r&3) + 8*(r>>2) + 4*lh -> x
         float* slab = a.out + (size_t)split * a.nx * KP;
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int n = 0; n < NT2; ++n)
 #pragma unroll
-            for (int n = 0; n < NT2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int x = x0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (x < a.nx) slab[(size_t)x * KP + 32 * n + li] = Z[b][n][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int xr = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (xr < a.nx) slab[(size_t)xr * KP + 32 * n + li] = Z[n][r];
+            }
+        if (MODE == MODE_FDH && lh == 0 && xok) a.mpart[(size_t)split * a.nx + x] = any_tile ? m_eff : NEG_BIG;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // operand preparation
 // ------------------------------------------------------------------------------------------------
-// fp32 [n][160] -> bf16 row-major copy [n_pad][160] and transposed copy [160][ldt]; optional "ones"
-// column (col 150 := 1.0) used to get the bias gradient out of GEMM2; rows >= n are zero.
-__global__ void proj_prep_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                 unsigned short* __restrict__ dstT, int n, int n_pad, int ldt, int ones_col) {
+// Column position of y inside the Y^T copy: GEMM2's k-order swaps bits 2 and 3 of the index.
+__device__ __forceinline__ int korder(int y) { return (y & ~12) | ((y & 4) << 1) | ((y & 8) >> 1); }
+
+// fp32 [n][160] -> the three bf16 copies (plain [n_pad][160], scaled by log2e [n_pad][160], transposed
+// [160][ldt]) with the constant columns of the file header.  ROWS = 1: decoder hidden rows (h2b, h2s, h2tb);
+// ROWS = 0: items (w3b, w3s, w3tb), bias = b3.
+template <int ROWS>
+__global__ void proj_prep_kernel(const float* __restrict__ src, const float* __restrict__ bias,
+                                 unsigned short* __restrict__ dst, unsigned short* __restrict__ dsts,
+                                 unsigned short* __restrict__ dstT, int n, int n_pad, int ldt) {
     __shared__ unsigned short tile[32][KP + 2];
     const int r0 = blockIdx.x * 32;
+    const unsigned short one = 0x3F80;
     for (int i = threadIdx.x; i < 32 * KP; i += blockDim.x) {
         const int r = i / KP, c = i % KP;
-        float v = 0.f;
-        if (r0 + r < n) {
-            v = src[(size_t)(r0 + r) * KP + c];
-            if (c == ones_col) v = 1.0f;
+        const int row = r0 + r;
+        const bool live = row < n;
+        unsigned short hp = 0, hs = 0;          // plain copy, scaled copy
+        if (c < SV_D) {
+            if (live) {
+                const float v = src[(size_t)row * KP + c];
+                hp = sv_f2bf(v);
+                hs = sv_f2bf(v * LOG2E);
+            }
+        } else if (ROWS) {
+            if (c == C_ONE) hp = live ? one : 0;
+            if (c == C_BH || c == C_BL) { hp = live ? one : 0; hs = live ? one : 0; }
+            if (c == C_RH) hp = live ? 0 : sv_f2bf(NEG_BIG);      // live rows: written by the forward finish
+        } else {
+            if (c == C_BH || c == C_BL) {
+                if (live) {
+                    const float b = bias[row] * LOG2E;
+                    const unsigned short hi = sv_f2bf(b);
+                    hp = hs = (c == C_BH) ? hi : sv_f2bf(b - sv_bf2f(hi));
+                } else if (c == C_BH) {
+                    hp = sv_f2bf(NEG_BIG);
+                }
+            }
+            if (c == C_RH || c == C_RL) hs = live ? one : 0;
+            if (c == C_MH || c == C_ML) hp = one;
         }
-        const unsigned short h = sv_f2bf(v);
-        tile[r][c] = h;
-        if (r0 + r < n_pad) dst[(size_t)(r0 + r) * KP + c] = h;
+        tile[r][c] = hp;
+        if (row < n_pad) {
+            dst[(size_t)row * KP + c] = hp;
+            dsts[(size_t)row * KP + c] = hs;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * KP; i += blockDim.x) {
         const int c = i / 32, r = i % 32;
-        if (r0 + r < ldt) dstT[(size_t)c * ldt + r0 + r] = tile[r][c];
+        if (r0 + r < ldt) dstT[(size_t)c * ldt + korder(r0 + r)] = tile[r][c];
     }
 }
 
-// ky for FWD / DH: bias (pads -> -1e30).  kx for DW: bias * log2e.
-__global__ void proj_bias_consts_kernel(const float* __restrict__ b3, float* __restrict__ ky_items,
-                                        float* __restrict__ kx_items, int I, int I_pad) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= I_pad) return;
-    const float b = i < I ? b3[i] : NEG_BIG;
-    ky_items[i] = b;
-    if (i < I) kx_items[i] = b * LOG2E;
-}
-
-// Forward finish, one wave per row: lse from the NSPLIT partials, target logits by fp32 dot products,
-// nll_row, and the exponent constants of the backward kernels.
+// Loss-only forward finish, one wave per row: lse from the NSPLIT partials (log2 units), target logits by fp32
+// dot products, nll_row.
 __global__ void proj_fwd_finish_kernel(const float2* __restrict__ part, const float* __restrict__ h2,
                                        const float* __restrict__ w3, const float* __restrict__ b3,
-                                       const int* __restrict__ tgt, const float* __restrict__ w_nll, int R, int K,
-                                       float* __restrict__ nll_row, float* __restrict__ lse_out,
-                                       float* __restrict__ kx_rows, float* __restrict__ ky_rows, int R_pad) {
+                                       const int* __restrict__ tgt, int R, int K, float* __restrict__ nll_row,
+                                       float* __restrict__ lse_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= R_pad) return;
-    if (row >= R) {
-        if (lane == 0) ky_rows[row] = NEG_BIG;
-        return;
-    }
+    if (row >= R) return;
     float m = NEG_BIG, l = 0.f;
     if (lane < NSPLIT) {
         const float2 p = part[(size_t)lane * R + row];
         m = p.x; l = p.y;
     }
     const float M = sv_wave_max(m);
-    l = sv_wave_sum(l * expf(m - M));
-    const float lse = M + logf(l);
+    l = sv_wave_sum(l * exp2f(m - M));
+    const float lse = (M + log2f(l)) * LN2;
     float nll = 0.f;
-    int nr = 0;
     const float* hr = h2 + (size_t)row * KP;
     for (int k = 0; k < K; ++k) {
         const int it = tgt[(size_t)row * K + k];     // wave-uniform
@@ -345,45 +365,77 @@ __global__ void proj_fwd_finish_kernel(const float2* __restrict__ part, const fl
         for (int c = lane; c < SV_D; c += 64) d += hr[c] * wr[c];
         d = sv_wave_sum(d) + b3[it];
         nll += lse - d;
-        ++nr;
     }
     if (lane == 0) {
         nll_row[row] = nll;
         lse_out[row] = lse;
-        const float c = (float)nr * w_nll[row];
-        kx_rows[row] = log2f(c) - lse * LOG2E;
-        ky_rows[row] = logf(c) - lse;
     }
 }
 
-// dL/dh2 finish: sum the NSPLIT slabs, subtract the target part w_r sum_k W3[tgt], apply tanh'.
-// One wave per row, float4 lanes 0..39.
-__global__ void proj_dh_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ w3,
-                                      const int* __restrict__ tgt, const float* __restrict__ w_nll,
-                                      const float* __restrict__ d1, float* __restrict__ dd1, int R, int K) {
+// FDH finish, one wave per row (float4 lanes 0..39): combine the NSPLIT (m, Z) partials, lse and NLL, the
+// target part of dL/dh2, tanh', and the row constant log2(c_r) - lse2_r of the weight-gradient kernel
+// (bf16 hi/lo into columns 153/154 of h2b).
+__global__ void proj_fdh_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ mpart,
+                                       const float* __restrict__ h2, const float* __restrict__ w3,
+                                       const float* __restrict__ b3, const int* __restrict__ tgt,
+                                       const float* __restrict__ w_nll, int R, int K, float* __restrict__ dd1,
+                                       float* __restrict__ nll_row, float* __restrict__ lse_out,
+                                       unsigned short* __restrict__ h2b) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= R || lane >= KP / 4) return;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= R) return;
+    const int ln = lane < KP / 4 ? lane : 0;
+    float ms[NSPLIT];
+    float M = NEG_BIG;
+#pragma unroll
     for (int z = 0; z < NSPLIT; ++z) {
-        const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * R + row) * KP)[lane];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        ms[z] = mpart[(size_t)z * R + row];
+        M = fmaxf(M, ms[z]);
     }
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int z = 0; z < NSPLIT; ++z) {
+        const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * R + row) * KP)[ln];
+        const float f = exp2f(ms[z] - M);
+        u.x += f * v.x; u.y += f * v.y; u.z += f * v.z; u.w += f * v.w;
+    }
+    const float l = __shfl(u.w, C_MH / 4, 64);            // column 155 = sum of P
+    const float lse2 = M + log2f(l);
+    const float lse = lse2 * LN2;
     const float w = w_nll[row];
+    const float4 hv = reinterpret_cast<const float4*>(h2 + (size_t)row * KP)[ln];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float nll = 0.f;
+    int nr = 0;
     for (int k = 0; k < K; ++k) {
-        const int it = tgt[(size_t)row * K + k];
+        const int it = tgt[(size_t)row * K + k];     // wave-uniform
         if (it < 0) continue;
-        const float4 v = reinterpret_cast<const float4*>(w3 + (size_t)it * KP)[lane];
-        s.x -= w * v.x; s.y -= w * v.y; s.z -= w * v.z; s.w -= w * v.w;
+        const float4 wv = reinterpret_cast<const float4*>(w3 + (size_t)it * KP)[ln];
+        float d = lane < KP / 4 ? hv.x * wv.x + hv.y * wv.y + hv.z * wv.z + hv.w * wv.w : 0.f;   // pads are zero
+        d = sv_wave_sum(d) + b3[it];
+        nll += lse - d;
+        ++nr;
+        acc.x += wv.x; acc.y += wv.y; acc.z += wv.z; acc.w += wv.w;
     }
-    const float4 y = reinterpret_cast<const float4*>(d1 + (size_t)row * KP)[lane];
-    float4 o;
-    const int c0 = 4 * lane;
-    o.x = c0 + 0 < SV_D ? s.x * (1.0f - y.x * y.x) : 0.f;
-    o.y = c0 + 1 < SV_D ? s.y * (1.0f - y.y * y.y) : 0.f;
-    o.z = c0 + 2 < SV_D ? s.z * (1.0f - y.z * y.z) : 0.f;
-    o.w = c0 + 3 < SV_D ? s.w * (1.0f - y.w * y.w) : 0.f;
-    reinterpret_cast<float4*>(dd1 + (size_t)row * KP)[lane] = o;
+    const float c = (float)nr * w;
+    const float sc = c / l;
+    if (lane < KP / 4) {
+        float4 o;
+        const int c0 = 4 * lane;
+        o.x = c0 + 0 < SV_D ? (sc * u.x - w * acc.x) * (1.0f - hv.x * hv.x) : 0.f;
+        o.y = c0 + 1 < SV_D ? (sc * u.y - w * acc.y) * (1.0f - hv.y * hv.y) : 0.f;
+        o.z = c0 + 2 < SV_D ? (sc * u.z - w * acc.z) * (1.0f - hv.z * hv.z) : 0.f;
+        o.w = c0 + 3 < SV_D ? (sc * u.w - w * acc.w) * (1.0f - hv.w * hv.w) : 0.f;
+        reinterpret_cast<float4*>(dd1 + (size_t)row * KP)[lane] = o;
+    }
+    if (lane == 0) {
+        nll_row[row] = nll;
+        lse_out[row] = lse;
+        const float rc = nr > 0 ? log2f(c) - lse2 : NEG_BIG;
+        const unsigned short hi = sv_f2bf(rc);
+        h2b[(size_t)row * KP + C_RH] = hi;
+        h2b[(size_t)row * KP + C_RL] = sv_f2bf(rc - sv_bf2f(hi));
+    }
 }
 
 // dL/dW3, dL/db3 finish: one workgroup per item.  Wave 0 sums the slabs; the item's target occurrences
@@ -454,19 +506,18 @@ __global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __rest
     reinterpret_cast<float4*>(gw3 + (size_t)it * KP)[lane] = t;
 }
 
-constexpr int PROJ_NB = 1;   // x sub-tiles per wave of the backward kernels (see proj_kernel)
-
 template <int MODE>
-int launch_proj(const ProjArgs& a, hipStream_t st) {
-    const int lds = 2 * STAGE_BYTES;
+int launch_proj(ProjArgs a, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)proj_kernel<MODE, PROJ_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)proj_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return svae_fail((int)e, "svae_proj: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
+    const int ntiles = (a.ny + BY - 1) / BY;
+    a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
     const int xt = (a.nx + BX - 1) / BX;
-    hipLaunchKernelGGL((proj_kernel<MODE, PROJ_NB>), dim3(xt * NSPLIT), dim3(512 / PROJ_NB), lds, st, a);
+    hipLaunchKernelGGL((proj_kernel<MODE>), dim3(xt * NSPLIT), dim3(512), LDS_BYTES, st, a);
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -476,87 +527,91 @@ int launch_proj(const ProjArgs& a, hipStream_t st) {
 extern "C" int svae_proj_nsplit(void) { return NSPLIT; }
 extern "C" int svae_proj_tile(void) { return BY; }
 
-// bf16 operand copies.  dst [n_pad][160], dstT [160][ldt]; n_pad and ldt are multiples of 64, >= n.
-extern "C" int svae_proj_prep(const float* src, void* dst, void* dstT, int n, int n_pad, int ldt, int ones_col,
-                              void* stream) {
-    SV_CHECK_ARG(src && dst && dstT && n > 0 && n_pad >= n && ldt >= n_pad && (n_pad % BY) == 0 && (ldt % 8) == 0,
-                 "svae_proj_prep: bad arguments");
-    hipLaunchKernelGGL(proj_prep_kernel, dim3((ldt + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
-                       (unsigned short*)dst, (unsigned short*)dstT, n, n_pad, ldt, ones_col);
+// bf16 operand copies of the decoder hidden rows (fp32 h2 [R][160], the tanh output of Decoder.linear1 nb:709):
+// h2b [R_pad][160] plain, h2s [R_pad][160] scaled by log2(e), h2tb [160][R_pad] transposed; R_pad % 64 == 0.
+extern "C" int svae_proj_prep_rows(const float* h2, int R, int R_pad, void* h2b, void* h2s, void* h2tb,
+                                   void* stream) {
+    SV_CHECK_ARG(h2 && h2b && h2s && h2tb && R > 0 && R_pad >= R && (R_pad % BY) == 0, "svae_proj_prep_rows: bad arguments");
+    hipLaunchKernelGGL(proj_prep_kernel<1>, dim3(R_pad / 32), dim3(256), 0, (hipStream_t)stream, h2, (const float*)nullptr,
+                       (unsigned short*)h2b, (unsigned short*)h2s, (unsigned short*)h2tb, R, R_pad, R_pad);
     SV_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int svae_proj_bias_consts(const float* b3, float* ky_items, float* kx_items, int I, int I_pad,
-                                     void* stream) {
-    SV_CHECK_ARG(b3 && ky_items && kx_items && I > 0 && I_pad >= I, "svae_proj_bias_consts: bad arguments");
-    hipLaunchKernelGGL(proj_bias_consts_kernel, dim3((I_pad + 255) / 256), dim3(256), 0, (hipStream_t)stream, b3,
-                       ky_items, kx_items, I, I_pad);
+// bf16 operand copies of Decoder.linear2 (nb:704): w3 [I][160] fp32, b3 [I]  ->  w3b, w3s [I_pad][160],
+// w3tb [160][I_pad]; I_pad % 64 == 0.
+extern "C" int svae_proj_prep_items(const float* w3, const float* b3, int I, int I_pad, void* w3b, void* w3s,
+                                    void* w3tb, void* stream) {
+    SV_CHECK_ARG(w3 && b3 && w3b && w3s && w3tb && I > 0 && I_pad >= I && (I_pad % BY) == 0, "svae_proj_prep_items: bad arguments");
+    hipLaunchKernelGGL(proj_prep_kernel<0>, dim3(I_pad / 32), dim3(256), 0, (hipStream_t)stream, w3, b3,
+                       (unsigned short*)w3b, (unsigned short*)w3s, (unsigned short*)w3tb, I, I_pad, I_pad);
     SV_LAUNCH_CHECK();
     return 0;
 }
 
 // Reference interface replaced: Decoder.linear2 + F.log_softmax + likelihood of VAELoss.forward
-// (nb:710, nb:802-808), fused.  h2b = bf16 copy of the decoder hidden rows [R_pad][160], w3b / w3tb =
-// bf16 copies of W3 ([I_pad][160] and [160][ldt]); part = float2 [8][R] scratch.
-// Outputs: nll_row[R], lse[R], kx_rows[R], ky_rows[R_pad] (exponent constants for the backward).
-extern "C" int svae_proj_nll_fwd(const void* h2b, const void* w3b, const float* ky_items, const float* h2,
-                                 const float* w3, const float* b3, const int* tgt, const float* w_nll, int R,
-                                 int R_pad, int I, int K, float* part, float* nll_row, float* lse, float* kx_rows,
-                                 float* ky_rows, void* stream) {
-    SV_CHECK_ARG(h2b && w3b && ky_items && h2 && w3 && b3 && tgt && w_nll && part && nll_row && lse && kx_rows &&
-                     ky_rows, "svae_proj_nll_fwd: null pointer");
-    SV_CHECK_ARG(R > 0 && I > 0 && K >= 1 && R_pad >= R && (R_pad % BY) == 0, "svae_proj_nll_fwd: bad shape");
-    ProjArgs a{(const unsigned short*)h2b, (const unsigned short*)w3b, nullptr, nullptr, ky_items, part, R, I, 0, 0};
-    const int ntiles = (I + BY - 1) / BY;
-    a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
+// (nb:710, nb:802-808), loss only (scoring).  part = float2 [8][R] scratch.  Outputs nll_row[R], lse[R].
+extern "C" int svae_proj_nll_fwd(const void* h2s, const void* w3b, const float* h2, const float* w3, const float* b3,
+                                 const int* tgt, int R, int I, int K, float* part, float* nll_row, float* lse,
+                                 void* stream) {
+    SV_CHECK_ARG(h2s && w3b && h2 && w3 && b3 && tgt && part && nll_row && lse, "svae_proj_nll_fwd: null pointer");
+    SV_CHECK_ARG(R > 0 && I > 0 && K >= 1, "svae_proj_nll_fwd: bad shape");
+    ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, nullptr, part, nullptr, R, I, 0, 0};
     if (int e = launch_proj<MODE_FWD>(a, (hipStream_t)stream)) return e;
-    hipLaunchKernelGGL(proj_fwd_finish_kernel, dim3((R_pad + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const float2*)part, h2, w3, b3, tgt, w_nll, R, K, nll_row, lse, kx_rows, ky_rows, R_pad);
+    hipLaunchKernelGGL(proj_fwd_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)part, h2, w3, b3, tgt, R, K, nll_row, lse);
     SV_LAUNCH_CHECK();
     return 0;
 }
 
-// Reference interface replaced: autograd of the same (nb:1205).  Dense parts by the fused kernels, the
-// sparse target parts and tanh' (of Decoder.linear1's activation, nb:709) in the finish kernels.
-//   dd1 [R][160]  = dL/d(pre-tanh decoder hidden)       gw3 [I_pad][160], gb3 [I_pad]
-// slabs: scratch of 8 * max(R, I) * 160 floats.  occ_off [I+1] / occ_row: target occurrences by item.
-extern "C" int svae_proj_nll_bwd(const void* h2b, const void* h2tb, int ldt_rows, const void* w3b, const void* w3tb,
-                                 int ldt_items, const float* kx_rows, const float* ky_rows, const float* kx_items,
-                                 const float* ky_items, const float* h2, const float* w3, const int* tgt,
-                                 const float* w_nll, const int* occ_off, const int* occ_row, int R, int I, int I_pad,
-                                 int K, float* slabs, float* dd1, float* gw3, float* gb3, int parts, void* stream) {
-    SV_CHECK_ARG(h2b && h2tb && w3b && w3tb && kx_rows && ky_rows && kx_items && ky_items && h2 && w3 && tgt &&
-                     w_nll && occ_off && occ_row && slabs && dd1 && gw3 && gb3, "svae_proj_nll_bwd: null pointer");
-    SV_CHECK_ARG(R > 0 && I > 0 && I_pad >= I && K >= 1 && parts > 0 && parts < 16, "svae_proj_nll_bwd: bad shape");
+// Reference interface replaced: the same forward AND the hidden-side half of its autograd (nb:1205) in one
+// sweep over the items.  Outputs nll_row[R], lse[R], dd1 [R][160] = dL/d(pre-tanh decoder hidden) (tanh of
+// Decoder.linear1, nb:709), and the row constants in columns 153/154 of h2b that svae_proj_nll_bwd_dw needs.
+// slabs: scratch of 8 * R * 160 floats; mpart: 8 * R floats.  parts: 1 = sweep kernel, 2 = finish (3 = both).
+extern "C" int svae_proj_nll_fwd_dh(const void* h2s, void* h2b, const void* w3b, const void* w3tb, int I_pad,
+                                    const float* h2, const float* w3, const float* b3, const int* tgt,
+                                    const float* w_nll, int R, int I, int K, float* slabs, float* mpart,
+                                    float* nll_row, float* lse, float* dd1, int parts, void* stream) {
+    SV_CHECK_ARG(h2s && h2b && w3b && w3tb && h2 && w3 && b3 && tgt && w_nll && slabs && mpart && nll_row && lse && dd1,
+                 "svae_proj_nll_fwd_dh: null pointer");
+    SV_CHECK_ARG(R > 0 && I > 0 && K >= 1 && I_pad >= I && (I_pad % BY) == 0 && parts > 0 && parts < 4,
+                 "svae_proj_nll_fwd_dh: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    // parts: 1 = weight-gradient kernel, 2 = its finish, 4 = hidden-gradient kernel, 8 = its finish (15 = all;
-    // the pieces share `slabs`, so they must be enqueued in this order on one stream)
-    if (parts & 3) {   // dL/dW3, dL/db3:  X = items, Y = rows
-        ProjArgs a{(const unsigned short*)w3b, (const unsigned short*)h2b, (const unsigned short*)h2tb, kx_items,
-                   ky_rows, slabs, I, R, ldt_rows, 0};
-        const int ntiles = (R + BY - 1) / BY;
-        a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
-        if (parts & 1)
-            if (int e = launch_proj<MODE_DW>(a, st)) return e;
-        if (parts & 2) {
-            hipLaunchKernelGGL(proj_dw_finish_kernel, dim3(I_pad), dim3(256), 0, st, slabs, h2, w_nll, occ_off,
-                               occ_row, gw3, gb3, I, I_pad);
-            SV_LAUNCH_CHECK();
-        }
+    if (parts & 1) {
+        ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, (const unsigned short*)w3tb, slabs, mpart,
+                   R, I, I_pad, 0};
+        if (int e = launch_proj<MODE_FDH>(a, st)) return e;
     }
-    if (parts & 12) {   // dL/dh2:  X = rows, Y = items
-        ProjArgs a{(const unsigned short*)h2b, (const unsigned short*)w3b, (const unsigned short*)w3tb, kx_rows,
-                   ky_items, slabs, R, I, ldt_items, 0};
-        const int ntiles = (I + BY - 1) / BY;
-        a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
-        if (parts & 4)
-            if (int e = launch_proj<MODE_DH>(a, st)) return e;
-        if (parts & 8) {
-            hipLaunchKernelGGL(proj_dh_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, st, slabs, w3, tgt, w_nll, h2,
-                               dd1, R, K);
-            SV_LAUNCH_CHECK();
-        }
+    if (parts & 2) {
+        hipLaunchKernelGGL(proj_fdh_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, st, slabs, mpart, h2, w3, b3, tgt,
+                           w_nll, R, K, dd1, nll_row, lse, (unsigned short*)h2b);
+        SV_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// Reference interface replaced: the weight-side half of the autograd of the same (nb:1205): gw3 [I_pad][160],
+// gb3 [I_pad].  Needs svae_proj_nll_fwd_dh of the same batch before it (row constants in h2b).
+// slabs: scratch of 8 * I * 160 floats.  occ_off [I+1] / occ_row: target occurrences by item.
+// I_rows >= I: rows of gw3 / gb3 (rows >= I are written as zero).  parts: 1 = sweep kernel, 2 = finish (3 = both).
+extern "C" int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad,
+                                    int I, int I_rows, const float* h2, const float* w_nll, const int* occ_off,
+                                    const int* occ_row, float* slabs, float* gw3, float* gb3, int parts,
+                                    void* stream) {
+    SV_CHECK_ARG(w3s && h2b && h2tb && h2 && w_nll && occ_off && occ_row && slabs && gw3 && gb3,
+                 "svae_proj_nll_bwd_dw: null pointer");
+    SV_CHECK_ARG(R > 0 && I > 0 && I_rows >= I && R_pad >= R && (R_pad % BY) == 0 && parts > 0 && parts < 4,
+                 "svae_proj_nll_bwd_dw: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (parts & 1) {
+        ProjArgs a{(const unsigned short*)w3s, (const unsigned short*)h2b, (const unsigned short*)h2tb, slabs, nullptr,
+                   I, R, R_pad, 0};
+        if (int e = launch_proj<MODE_DW>(a, st)) return e;
+    }
+    if (parts & 2) {
+        hipLaunchKernelGGL(proj_dw_finish_kernel, dim3(I_rows), dim3(256), 0, st, slabs, h2, w_nll, occ_off, occ_row,
+                           gw3, gb3, I, I_rows);
+        SV_LAUNCH_CHECK();
     }
     return 0;
 }

@@ -64,6 +64,7 @@ class SVAEEngine:
         self.IPAD = (self.I + 63) // 64 * 64
         self.w3b = self.w3tb = None
         self._last_fused = False
+        self._fused_grad = False
         self._dtmp_extra = None
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.prof = None               # dict tag -> list of (start, end) torch.cuda.Event pairs
@@ -106,17 +107,16 @@ class SVAEEngine:
             capp = (cap + 63) // 64 * 64
             self.capp = capp
             self.ws["h2b"] = torch.zeros(capp * DP, **bf)
+            self.ws["h2s"] = torch.zeros(capp * DP, **bf)
             self.ws["h2tb"] = torch.zeros(DP * capp, **bf)
-            self.ws["kx_rows"] = torch.zeros(capp, **f32)
-            self.ws["ky_rows"] = torch.zeros(capp, **f32)
             self.ws["part"] = torch.zeros(8 * capp * 2, **f32)
-            self.ws["pslabs"] = torch.empty(8 * max(capp, self.IPAD) * DP, **f32)
-            self.ws["pslabs_side"] = torch.empty(8 * max(capp, self.IPAD) * DP, **f32)
+            self.ws["mpart"] = torch.zeros(8 * capp, **f32)
+            self.ws["pslabs"] = torch.empty(8 * capp * DP, **f32)
+            self.ws["pslabs_side"] = torch.empty(8 * self.IPAD * DP, **f32)
             if self.w3b is None:
                 self.w3b = torch.zeros(self.IPAD * DP, **bf)
+                self.w3s = torch.zeros(self.IPAD * DP, **bf)
                 self.w3tb = torch.zeros(DP * self.IPAD, **bf)
-                self.ky_items = torch.zeros(self.IPAD, **f32)
-                self.kx_items = torch.zeros(self.IPAD, **f32)
 
     def _ensure_logits(self):
         if self.ws["logits"].numel() < self.cap * self.IP:
@@ -211,14 +211,20 @@ class SVAEEngine:
         if self.fused and want_loss:
             self._last_fused = True
             self._proj_prepare(R)
-            Rp = (R + 63) // 64 * 64
-            ev = self._tic("proj_fwd")
-            _lib.call("svae_proj_nll_fwd", w["h2b"].data_ptr(), self.w3b.data_ptr(), self.ky_items.data_ptr(),
-                      w["d1"].data_ptr(), self.P("decoder.linear2.weight").data_ptr(),
-                      self.P("decoder.linear2.bias").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
-                      R, Rp, self.I, plan.K, w["part"].data_ptr(), w["nll_row"].data_ptr(), w["lse"].data_ptr(),
-                      w["kx_rows"].data_ptr(), w["ky_rows"].data_ptr(), st)
-            self._toc("proj_fwd", ev)
+            if want_grad:
+                # forward + hidden-side backward in one sweep over the items (dd1 is ready after this)
+                args = (w["h2s"].data_ptr(), w["h2b"].data_ptr(), self.w3b.data_ptr(), self.w3tb.data_ptr(),
+                        self.IPAD, w["d1"].data_ptr(), self.P("decoder.linear2.weight").data_ptr(),
+                        self.P("decoder.linear2.bias").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
+                        R, self.I, plan.K, w["pslabs"].data_ptr(), w["mpart"].data_ptr(), w["nll_row"].data_ptr(),
+                        w["lse"].data_ptr(), w["dd1"].data_ptr())
+                self._split_call("svae_proj_nll_fwd_dh", args, ((1, "proj_fdh_fused"), (2, "proj_fdh_finish")))
+            else:
+                _lib.call("svae_proj_nll_fwd", w["h2s"].data_ptr(), self.w3b.data_ptr(), w["d1"].data_ptr(),
+                          self.P("decoder.linear2.weight").data_ptr(), self.P("decoder.linear2.bias").data_ptr(),
+                          plan.tgt.data_ptr(), R, self.I, plan.K, w["part"].data_ptr(), w["nll_row"].data_ptr(),
+                          w["lse"].data_ptr(), st)
+            self._fused_grad = bool(want_grad)
             _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
             return self.loss_out
@@ -238,16 +244,25 @@ class SVAEEngine:
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
         return self.loss_out
 
+    def _split_call(self, name, args, parts):
+        """One C-ABI call covering several kernels; when profiling, one call per kernel so each is bracketed."""
+        if self.prof is None:
+            _lib.call(name, *args, sum(b for b, _ in parts), _stream())
+            return
+        for bit, tag in parts:
+            ev = self._tic(tag)
+            _lib.call(name, *args, bit, _stream())
+            self._toc(tag, ev)
+
     def _proj_prepare(self, R):
         """bf16 operand copies for the fused projection kernels (W3 changes every step)."""
         w, st = self.ws, _stream()
         Rp = (R + 63) // 64 * 64
-        _lib.call("svae_proj_prep", w["d1"].data_ptr(), w["h2b"].data_ptr(), w["h2tb"].data_ptr(), R, Rp, Rp,
-                  D, st)                                     # column 150 := 1.0 (bias-gradient column)
-        _lib.call("svae_proj_prep", self.P("decoder.linear2.weight").data_ptr(), self.w3b.data_ptr(),
-                  self.w3tb.data_ptr(), self.I, self.IPAD, self.IPAD, -1, st)
-        _lib.call("svae_proj_bias_consts", self.P("decoder.linear2.bias").data_ptr(), self.ky_items.data_ptr(),
-                  self.kx_items.data_ptr(), self.I, self.IPAD, st)
+        _lib.call("svae_proj_prep_rows", w["d1"].data_ptr(), R, Rp, w["h2b"].data_ptr(), w["h2s"].data_ptr(),
+                  w["h2tb"].data_ptr(), st)
+        _lib.call("svae_proj_prep_items", self.P("decoder.linear2.weight").data_ptr(),
+                  self.P("decoder.linear2.bias").data_ptr(), self.I, self.IPAD, self.w3b.data_ptr(),
+                  self.w3s.data_ptr(), self.w3tb.data_ptr(), st)
 
     def dense_logits(self, rows_idx=None):
         """Dense logits [n, I] for all rows of the last forward (rows_idx None) or a gathered subset
@@ -286,30 +301,21 @@ class SVAEEngine:
         if self._last_fused:
             if plan.occ_off is None:
                 raise ValueError("fused mode needs build_plan(..., total_items=I)")
+            if not self._fused_grad:
+                raise ValueError("backward() needs forward(..., want_grad=True)")
             Rp = (R + 63) // 64 * 64
 
-            def proj_bwd(parts, slabs, tags):
-                args = (w["h2b"].data_ptr(), w["h2tb"].data_ptr(), Rp, self.w3b.data_ptr(),
-                        self.w3tb.data_ptr(), self.IPAD, w["kx_rows"].data_ptr(), w["ky_rows"].data_ptr(),
-                        self.kx_items.data_ptr(), self.ky_items.data_ptr(), w["d1"].data_ptr(),
-                        self.P("decoder.linear2.weight").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
-                        plan.occ_off.data_ptr(), plan.occ_row.data_ptr(), R, I, IP, plan.K, slabs.data_ptr(),
-                        w["dd1"].data_ptr(), self.Gv("decoder.linear2.weight").data_ptr(),
+            def proj_dw(slabs):
+                args = (self.w3s.data_ptr(), w["h2b"].data_ptr(), w["h2tb"].data_ptr(), R, Rp, I, IP,
+                        w["d1"].data_ptr(), plan.w_nll.data_ptr(), plan.occ_off.data_ptr(), plan.occ_row.data_ptr(),
+                        slabs.data_ptr(), self.Gv("decoder.linear2.weight").data_ptr(),
                         self.Gv("decoder.linear2.bias").data_ptr())
-                if self.prof is None:
-                    _lib.call("svae_proj_nll_bwd", *args, parts, _stream())
-                else:       # profiling: bracket each kernel of the call on its own
-                    for bit, tag in tags:
-                        ev = self._tic(tag)
-                        _lib.call("svae_proj_nll_bwd", *args, bit, _stream())
-                        self._toc(tag, ev)
+                self._split_call("svae_proj_nll_bwd_dw", args, ((1, "proj_dw_fused"), (2, "proj_dw_finish")))
 
             if self.overlap:
                 side = self._side_stream()
-                proj_bwd(12, w["pslabs"], ((4, "proj_dh_fused"), (8, "proj_dh_finish")))
             else:
-                proj_bwd(15, w["pslabs"], ((1, "proj_dw_fused"), (2, "proj_dw_finish"), (4, "proj_dh_fused"),
-                                           (8, "proj_dh_finish")))
+                proj_dw(w["pslabs_side"])
                 self._bucket(0)
         else:
             dl = w["logits"]
@@ -351,7 +357,7 @@ class SVAEEngine:
             # first; the weight-gradient kernels then take whatever the recurrence leaves idle
             side.wait_event(chain_done)
             with torch.cuda.stream(side):
-                proj_bwd(3, w["pslabs_side"], ((1, "proj_dw_fused"), (2, "proj_dw_finish")))
+                proj_dw(w["pslabs_side"])
                 self._bucket(0)
                 decoder_side_wgrads(self.slabs_side)
         self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
