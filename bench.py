@@ -88,7 +88,7 @@ def main():
     for _ in range(args.warmup):
         eng.train_step(plans[step % len(plans)], 0.01, seed=1234)
         step += 1
-    tags = ["proj_fwd", "proj_fdh_fused", "proj_fdh_finish", "proj_dw_fused", "proj_dw_finish", "proj_dw", "proj_dx",
+    tags = ["mlp_fwd", "mlp_bwd", "proj_fwd", "proj_fdh_fused", "proj_fdh_finish", "proj_dw_fused", "proj_dw_finish", "proj_dw", "proj_dx",
             "softmax_nll", "gru_fwd", "gru_bwd"]
     eng.prof = {t: [] for t in tags}
     barrier()

@@ -75,6 +75,20 @@ int svae_latent_bwd(const float* tmp, const float* eps, const float* dz, const f
 int svae_philox_normal(float* out, const long long* row_key, int R, unsigned long long seed, unsigned step,
                        void* stream);
 
+/* ---- fused row-wise MLP chain (bf16 MFMA path) --------------------------------------------------------
+ * svae_mlp_fwd replaces Encoder.forward nb:693-696, Model.sample_latent nb:734-750, the KL row term of
+ * VAELoss nb:797 and Decoder.linear1 + tanh nb:708-709 in one kernel: hs [R][224] -> enc [R][160],
+ * tmp [R][128] = (mu | log_sigma), z [R][64], d1 [R][160], kl_row [R].  svae_mlp_bwd replaces their autograd
+ * (data gradients, nb:1205): dd1 [R][160] -> dtmp [R][128], denc [R][160], dhs [R][224].
+ * svae_mlp_prep lays the three weights out as bf16 MFMA fragments (svae_mlp_frag_elems() elements); call it
+ * whenever the weights changed.  See csrc/mlp.hip. */
+int svae_mlp_frag_elems(void);
+int svae_mlp_prep(const float* w1, const float* wl, const float* w2, void* frags, void* stream);
+int svae_mlp_fwd(const float* hs, const float* eps, const void* frags, const float* b1, const float* bl,
+                 const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R, void* stream);
+int svae_mlp_bwd(const float* dd1, const float* tmp, const float* eps, const float* enc, const float* w_kl,
+                 const void* frags, float anneal, float* dtmp, float* denc, float* dhs, int R, void* stream);
+
 /* ---- loss over materialised logits (fp32 path) ------------------------------------------------------
  * Replaces F.log_softmax nb:802 + likelihood nb:805-808 (+ their gradient when write_grad != 0:
  * logits are overwritten by w_nll[r] * (n_r softmax - y)).  tgt [R][K] int32, -1 = padding. */

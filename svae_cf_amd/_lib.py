@@ -40,6 +40,10 @@ SIGNATURES = {
     "svae_proj_nll_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "svae_proj_nll_fwd_dh": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "svae_proj_nll_bwd_dw": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "svae_mlp_frag_elems": [],
+    "svae_mlp_prep": [_P, _P, _P, _P, _P],
+    "svae_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "svae_mlp_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "svae_proj_nsplit": [],
     "svae_proj_tile": [],
     "svae_check_device": [],

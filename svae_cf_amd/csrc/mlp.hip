@@ -1,0 +1,372 @@
+// The row-wise MLP chain between the GRU and the |items|-wide projection, fused, for gfx950 (bf16 MFMA,
+// fp32 accumulate), forward and backward:
+//
+//   forward   enc = tanh(W1 h + b1)          Encoder.forward nb:693-696          [R,224] -> [R,160]
+//             tmp = Wl enc + bl = (mu | ls)  Model.sample_latent nb:738-741      -> [R,128]
+//             z   = mu + exp(ls) eps,  KL    nb:743-750, VAELoss nb:797          -> [R,64], kl_row[R]
+//             d1  = tanh(W2 z + b2)          Decoder.linear1 + tanh nb:708-709   -> [R,160]
+//   backward  dz = W2^T dd1;  dtmp = latent'(dz);  denc = (Wl^T dtmp) (1 - enc^2);  dhs = W1^T denc
+//             (autograd of the same at loss.backward() nb:1205; weight gradients are separate GEMMs)
+//
+// One wave owns 32 rows for the whole chain and never leaves its registers between layers: every
+// layer is computed TRANSPOSED, C^T[n][r] = sum_k W[n][k] act[k][r], with the weights as the MFMA A
+// operand and the activations as the B operand, so a data row sits on a LANE and the features on the
+// REGISTER index.  The fp32 accumulator tile of one layer, converted to bf16 in place, is exactly a B
+// operand of the next layer; the k-order it implies (kmap_acc below) is baked into the weight
+// fragments, which svae_mlp_prep lays out fragment-major (one fully coalesced 1 KiB load per fragment).
+// As separate launches of the generic GEMM these were 8 latency-bound kernels of 35-40 us each.
+#include "common.h"
+
+namespace {
+
+constexpr int KS_H = SV_HP / 16;    // 14 k-steps over the GRU state
+constexpr int KS_D = SV_DP / 16;    // 10 k-steps over a hidden layer
+constexpr int KS_L2 = SV_L2 / 16;   // 8  k-steps over (mu | ls)
+constexpr int KS_L = SV_L / 16;     // 4  k-steps over z
+constexpr int NT_D = SV_DP / 32;    // 5 n-tiles of a hidden layer
+constexpr int NT_L2 = SV_L2 / 32;   // 4
+constexpr int NT_L = SV_L / 32;     // 2
+constexpr int NT_H = SV_HP / 32;    // 7
+// fragment images, in units of fragments (64 lanes x 8 bf16 = 1 KiB each)
+constexpr int OFF_F1 = 0;                          // [NT_D][KS_H]   W1[n][k]      k natural
+constexpr int OFF_F2 = OFF_F1 + NT_D * KS_H;       // [NT_L2][KS_D]  Wl[n][k]      k in accumulator order
+constexpr int OFF_F3 = OFF_F2 + NT_L2 * KS_D;      // [NT_D][KS_L]   W2[n][k]      k in accumulator order
+constexpr int OFF_B1 = OFF_F3 + NT_D * KS_L;       // [NT_L][KS_D]   W2[k][n]      k natural
+constexpr int OFF_B2 = OFF_B1 + NT_L * KS_D;       // [NT_D][KS_L2]  Wl[k][n]      k in accumulator order
+constexpr int OFF_B3 = OFF_B2 + NT_D * KS_L2;      // [NT_H][KS_D]   W1[k][n]      k in accumulator order
+constexpr int NFRAG = OFF_B3 + NT_H * KS_D;        // 260
+
+// k index of element j of a lane's 8-element fragment (lane half lh) at k-step s
+__device__ __forceinline__ int kmap_nat(int s, int lh, int j) { return 16 * s + 8 * lh + j; }
+// ... when the B operand is a converted 32x32 accumulator: register rr of half lh holds row (rr&3) + 8 (rr>>2) + 4 lh
+__device__ __forceinline__ int kmap_acc(int s, int lh, int j) { return 16 * s + (j & 3) + 8 * (j >> 2) + 4 * lh; }
+
+__global__ void mlp_prep_kernel(const float* __restrict__ w1, const float* __restrict__ wl,
+                                const float* __restrict__ w2, unsigned short* __restrict__ frags) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = gid >> 6, lane = gid & 63;
+    if (f >= NFRAG) return;
+    const int li = lane & 31, lh = lane >> 5;
+    unsigned short v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float x;
+        if (f < OFF_F2) {
+            const int nt = (f - OFF_F1) / KS_H, s = (f - OFF_F1) % KS_H;
+            x = w1[(size_t)(32 * nt + li) * SV_HP + kmap_nat(s, lh, j)];
+        } else if (f < OFF_F3) {
+            const int nt = (f - OFF_F2) / KS_D, s = (f - OFF_F2) % KS_D;
+            x = wl[(size_t)(32 * nt + li) * SV_DP + kmap_acc(s, lh, j)];
+        } else if (f < OFF_B1) {
+            const int nt = (f - OFF_F3) / KS_L, s = (f - OFF_F3) % KS_L;
+            x = w2[(size_t)(32 * nt + li) * SV_L + kmap_acc(s, lh, j)];
+        } else if (f < OFF_B2) {
+            const int nt = (f - OFF_B1) / KS_D, s = (f - OFF_B1) % KS_D;
+            x = w2[(size_t)kmap_nat(s, lh, j) * SV_L + 32 * nt + li];
+        } else if (f < OFF_B3) {
+            const int nt = (f - OFF_B2) / KS_L2, s = (f - OFF_B2) % KS_L2;
+            x = wl[(size_t)kmap_acc(s, lh, j) * SV_DP + 32 * nt + li];
+        } else {
+            const int nt = (f - OFF_B3) / KS_D, s = (f - OFF_B3) % KS_D;
+            x = w1[(size_t)kmap_acc(s, lh, j) * SV_HP + 32 * nt + li];
+        }
+        v[j] = sv_f2bf(x);
+    }
+    uint4 u;
+    u.x = v[0] | ((unsigned)v[1] << 16); u.y = v[2] | ((unsigned)v[3] << 16);
+    u.z = v[4] | ((unsigned)v[5] << 16); u.w = v[6] | ((unsigned)v[7] << 16);
+    reinterpret_cast<uint4*>(frags)[(size_t)f * 64 + lane] = u;
+}
+
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+    const bf16v2 h = __builtin_convertvector((f32x2){a, b}, bf16v2);
+    return __builtin_bit_cast(unsigned, h);
+}
+// an accumulator tile -> the two B fragments (k-steps 2T, 2T+1) of the next layer
+__device__ __forceinline__ void to_frags(const f32x16& c, bf16x8& f0, bf16x8& f1) {
+    uint4 a, b;
+    a.x = pk2(c[0], c[1]);   a.y = pk2(c[2], c[3]);   a.z = pk2(c[4], c[5]);   a.w = pk2(c[6], c[7]);
+    b.x = pk2(c[8], c[9]);   b.y = pk2(c[10], c[11]); b.z = pk2(c[12], c[13]); b.w = pk2(c[14], c[15]);
+    f0 = __builtin_bit_cast(bf16x8, a);
+    f1 = __builtin_bit_cast(bf16x8, b);
+}
+// fragment f of the kernel's LDS-resident image (lane-linear 16-byte reads: conflict-free)
+__device__ __forceinline__ bf16x8 frag_ld(const char* lds, int f, int lane) {
+    return *reinterpret_cast<const bf16x8*>(lds + f * 1024 + lane * 16);
+}
+// The kernel's weight fragments (nfrag x 1 KiB, contiguous in HBM from fragment `first`) go to LDS by LDS-DMA,
+// one wave-instruction per fragment, spread over the block's 4 waves.  Straight from L2 every MFMA waited
+// for its own fragment load (about 130 dependent L2 round trips per wave: 40 us for a 5 us kernel).
+__device__ __forceinline__ void stage_frags(const unsigned short* frags, int first, int nfrag, char* lds, int wave, int lane) {
+    const char* g = reinterpret_cast<const char*>(frags) + (size_t)first * 1024 + lane * 16;
+    for (int f = wave; f < nfrag; f += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + f * 1024),
+                                         (__attribute__((address_space(3))) void*)(lds + f * 1024), 16, 0, 0);
+}
+constexpr int NFRAG_FWD = OFF_B1 - OFF_F1;     // 130
+constexpr int NFRAG_BWD = NFRAG - OFF_B1;      // 130
+constexpr int MLP_ROWS = 128;                  // rows per block (4 waves x 32)
+// natural-order B fragment from an fp32 row: 8 consecutive floats
+__device__ __forceinline__ bf16x8 row_frag(const float* p) {
+    const float4 lo = *reinterpret_cast<const float4*>(p);
+    const float4 hi = *reinterpret_cast<const float4*>(p + 4);
+    uint4 u;
+    u.x = pk2(lo.x, lo.y); u.y = pk2(lo.z, lo.w); u.z = pk2(hi.x, hi.y); u.w = pk2(hi.z, hi.w);
+    return __builtin_bit_cast(bf16x8, u);
+}
+// accumulator tile initialised with a per-feature bias: register group g holds features 32 nt + 8 g + 4 lh + 0..3
+__device__ __forceinline__ void bias_init(f32x16& c, const float* bias, int nt, int lh) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + 32 * nt + 8 * g + 4 * lh);
+        c[4 * g + 0] = b.x; c[4 * g + 1] = b.y; c[4 * g + 2] = b.z; c[4 * g + 3] = b.w;
+    }
+}
+__device__ __forceinline__ void tile_store(float* dst_row, int nt, int lh, const f32x16& c, bool ok) {
+    if (!ok) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst_row + 32 * nt + 8 * g + 4 * lh) =
+            make_float4(c[4 * g + 0], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
+}
+
+struct MlpFwdArgs {
+    const float* hs;        // [R][224]
+    const float* eps;       // [R][64]
+    const unsigned short* frags;
+    const float* b1;        // [160]
+    const float* bl;        // [128]
+    const float* b2;        // [160]
+    float* enc;             // [R][160]
+    float* tmp;             // [R][128]
+    float* z;               // [R][64]
+    float* d1;              // [R][160]
+    float* kl_row;          // [R]
+    int R;
+};
+
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int r = (blockIdx.x * 4 + wave) * 32 + li;
+    const bool ok = r < a.R;
+    const size_t rc = ok ? r : a.R - 1;          // loads are clamped, stores masked
+
+    // ---- encoder: enc^T = tanh(W1 hs^T + b1)
+    bf16x8 hb[KS_H];
+#pragma unroll
+    for (int s = 0; s < KS_H; ++s) hb[s] = row_frag(a.hs + rc * SV_HP + 16 * s + 8 * lh);
+    stage_frags(a.frags, OFF_F1, NFRAG_FWD, wlds, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8 pe[KS_D];
+#pragma unroll
+    for (int nt = 0; nt < NT_D; ++nt) {
+        f32x16 c;
+        bias_init(c, a.b1, nt, lh);
+#pragma unroll
+        for (int s = 0; s < KS_H; ++s)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_F1 + nt * KS_H + s, lane), hb[s], c, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = sv_tanh_fast(c[i]);
+        tile_store(a.enc + rc * SV_DP, nt, lh, c, ok);
+        to_frags(c, pe[2 * nt], pe[2 * nt + 1]);
+    }
+    // ---- (mu | ls)^T = Wl enc^T + bl
+    f32x16 t[NT_L2];
+#pragma unroll
+    for (int nt = 0; nt < NT_L2; ++nt) {
+        bias_init(t[nt], a.bl, nt, lh);
+#pragma unroll
+        for (int s = 0; s < KS_D; ++s)
+            t[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_F2 + nt * KS_D + s, lane), pe[s], t[nt], 0, 0, 0);
+        tile_store(a.tmp + rc * SV_L2, nt, lh, t[nt], ok);
+    }
+    // ---- z = mu + exp(ls) eps, KL row term (log_sigma is a log-std for sampling and a log-variance in KL:
+    //      reproduced as the reference has it, nb:743 / nb:797)
+    bf16x8 pz[KS_L];
+    float kl = 0.f;
+#pragma unroll
+    for (int q = 0; q < NT_L; ++q) {
+        f32x16 zt;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 e = *reinterpret_cast<const float4*>(a.eps + rc * SV_L + 32 * q + 8 * g + 4 * lh);
+            const float ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float mu = t[q][4 * g + c], ls = t[q + 2][4 * g + c];
+                const float sg = __builtin_amdgcn_exp2f(ls * 1.4426950408889634f);
+                zt[4 * g + c] = mu + sg * ev[c];
+                kl += 0.5f * (-ls + sg + mu * mu - 1.0f);
+            }
+        }
+        tile_store(a.z + rc * SV_L, q, lh, zt, ok);
+        to_frags(zt, pz[2 * q], pz[2 * q + 1]);
+    }
+    kl += __shfl_xor(kl, 32, 64);
+    if (ok && lh == 0) a.kl_row[r] = kl;
+    // ---- decoder hidden: d1^T = tanh(W2 z^T + b2)
+#pragma unroll
+    for (int nt = 0; nt < NT_D; ++nt) {
+        f32x16 c;
+        bias_init(c, a.b2, nt, lh);
+#pragma unroll
+        for (int s = 0; s < KS_L; ++s)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_F3 + nt * KS_L + s, lane), pz[s], c, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = sv_tanh_fast(c[i]);
+        tile_store(a.d1 + rc * SV_DP, nt, lh, c, ok);
+    }
+}
+
+struct MlpBwdArgs {
+    const float* dd1;       // [R][160]  dL/d(pre-tanh decoder hidden)
+    const float* tmp;       // [R][128]
+    const float* eps;       // [R][64]
+    const float* enc;       // [R][160]
+    const float* w_kl;      // [R]
+    const unsigned short* frags;
+    float* dtmp;            // [R][128]
+    float* denc;            // [R][160]  dL/d(pre-tanh encoder hidden)
+    float* dhs;             // [R][224]
+    float anneal;
+    int R;
+};
+
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int r = (blockIdx.x * 4 + wave) * 32 + li;
+    const bool ok = r < a.R;
+    const size_t rc = ok ? r : a.R - 1;
+
+    // ---- dz^T = W2^T dd1^T
+    bf16x8 db[KS_D];
+#pragma unroll
+    for (int s = 0; s < KS_D; ++s) db[s] = row_frag(a.dd1 + rc * SV_DP + 16 * s + 8 * lh);
+    stage_frags(a.frags, OFF_B1, NFRAG_BWD, wlds, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 dz[NT_L];
+#pragma unroll
+    for (int nt = 0; nt < NT_L; ++nt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dz[nt][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS_D; ++s)
+            dz[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, nt * KS_D + s, lane), db[s], dz[nt], 0, 0, 0);
+    }
+    // ---- latent backward: dmu = dz + a w mu ;  dls = dz exp(ls) eps + a w 0.5 (exp(ls) - 1)
+    const float kw = a.anneal * a.w_kl[rc];
+    bf16x8 pd[KS_L2];
+#pragma unroll
+    for (int q = 0; q < NT_L; ++q) {
+        f32x16 dmu, dls;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 e = *reinterpret_cast<const float4*>(a.eps + rc * SV_L + 32 * q + 8 * g + 4 * lh);
+            const float4 m = *reinterpret_cast<const float4*>(a.tmp + rc * SV_L2 + 32 * q + 8 * g + 4 * lh);
+            const float4 l = *reinterpret_cast<const float4*>(a.tmp + rc * SV_L2 + SV_L + 32 * q + 8 * g + 4 * lh);
+            const float ev[4] = {e.x, e.y, e.z, e.w}, mv[4] = {m.x, m.y, m.z, m.w}, lv[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float sg = __builtin_amdgcn_exp2f(lv[c] * 1.4426950408889634f);
+                const float gz = dz[q][4 * g + c];
+                dmu[4 * g + c] = gz + kw * mv[c];
+                dls[4 * g + c] = gz * sg * ev[c] + kw * 0.5f * (sg - 1.0f);
+            }
+        }
+        tile_store(a.dtmp + rc * SV_L2, q, lh, dmu, ok);
+        tile_store(a.dtmp + rc * SV_L2, q + 2, lh, dls, ok);
+        to_frags(dmu, pd[2 * q], pd[2 * q + 1]);
+        to_frags(dls, pd[2 * (q + 2)], pd[2 * (q + 2) + 1]);
+    }
+    // ---- denc^T = (Wl^T dtmp^T) (1 - enc^2)
+    bf16x8 pn[KS_D];
+#pragma unroll
+    for (int nt = 0; nt < NT_D; ++nt) {
+        f32x16 c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS_L2; ++s)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_B2 - OFF_B1 + nt * KS_L2 + s, lane), pd[s], c, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 y = *reinterpret_cast<const float4*>(a.enc + rc * SV_DP + 32 * nt + 8 * g + 4 * lh);
+            c[4 * g + 0] *= 1.0f - y.x * y.x; c[4 * g + 1] *= 1.0f - y.y * y.y;
+            c[4 * g + 2] *= 1.0f - y.z * y.z; c[4 * g + 3] *= 1.0f - y.w * y.w;
+        }
+        tile_store(a.denc + rc * SV_DP, nt, lh, c, ok);
+        to_frags(c, pn[2 * nt], pn[2 * nt + 1]);
+    }
+    // ---- dhs^T = W1^T denc^T
+#pragma unroll
+    for (int nt = 0; nt < NT_H; ++nt) {
+        f32x16 c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS_D; ++s)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_B3 - OFF_B1 + nt * KS_D + s, lane), pn[s], c, 0, 0, 0);
+        tile_store(a.dhs + rc * SV_HP, nt, lh, c, ok);
+    }
+}
+
+}  // namespace
+
+extern "C" int svae_mlp_frag_elems(void) { return NFRAG * 512; }
+
+// bf16 weight fragments of the three Linear layers (weights padded as in the flat parameter buffer:
+// w1 [160][224] Encoder.linear1 nb:688, wl [128][160] Model.linear1 nb:729, w2 [160][64] Decoder.linear1 nb:701).
+// frags: svae_mlp_frag_elems() bf16 elements.  Call once per optimizer step (the weights change).
+extern "C" int svae_mlp_prep(const float* w1, const float* wl, const float* w2, void* frags, void* stream) {
+    SV_CHECK_ARG(w1 && wl && w2 && frags, "svae_mlp_prep: null pointer");
+    hipLaunchKernelGGL(mlp_prep_kernel, dim3((NFRAG * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, wl, w2,
+                       (unsigned short*)frags);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Reference interface replaced: Encoder.forward nb:693-696, Model.sample_latent nb:734-750, the KL row term of
+// VAELoss nb:797 and Decoder.linear1 + tanh nb:708-709, for R rows at once.
+extern "C" int svae_mlp_fwd(const float* hs, const float* eps, const void* frags, const float* b1, const float* bl,
+                            const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R,
+                            void* stream) {
+    SV_CHECK_ARG(hs && eps && frags && b1 && bl && b2 && enc && tmp && z && d1 && kl_row, "svae_mlp_fwd: null pointer");
+    SV_CHECK_ARG(R > 0, "svae_mlp_fwd: R = %d", R);
+    MlpFwdArgs a{hs, eps, (const unsigned short*)frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R};
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_FWD * 1024);
+        if (e != hipSuccess) return svae_fail((int)e, "svae_mlp_fwd: LDS attribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(mlp_fwd_kernel, dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_FWD * 1024, (hipStream_t)stream, a);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Reference interface replaced: autograd of the same chain at loss.backward() nb:1205 (data gradients; the
+// weight gradients are svae_gemm calls on dd1/z, dtmp/enc, denc/hs).  dd1 = dL/d(pre-tanh decoder hidden).
+extern "C" int svae_mlp_bwd(const float* dd1, const float* tmp, const float* eps, const float* enc,
+                            const float* w_kl, const void* frags, float anneal, float* dtmp, float* denc, float* dhs,
+                            int R, void* stream) {
+    SV_CHECK_ARG(dd1 && tmp && eps && enc && w_kl && frags && dtmp && denc && dhs, "svae_mlp_bwd: null pointer");
+    SV_CHECK_ARG(R > 0, "svae_mlp_bwd: R = %d", R);
+    MlpBwdArgs a{dd1, tmp, eps, enc, w_kl, (const unsigned short*)frags, dtmp, denc, dhs, anneal, R};
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_BWD * 1024);
+        if (e != hipSuccess) return svae_fail((int)e, "svae_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_BWD * 1024, (hipStream_t)stream, a);
+    SV_LAUNCH_CHECK();
+    return 0;
+}

@@ -45,6 +45,13 @@
 // (deterministic; no atomics).
 #include "common.h"
 
+#ifdef SV_PROJ_TIMING   // diagnostic build only (tools/proj_timing.py): phase stamps of waves 0 and 4 of block 0
+__device__ unsigned long long g_proj_dbg[3][2][8];
+__device__ unsigned long long g_proj_blk[3][4096][4];   // per block (wave 0): realtime at start, at end, loop cycles, tiles
+#define SV_TS(i_) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts_acc[i_] += now_ - ts_last; ts_last = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define SV_TS(i_)
+#endif
 namespace {
 
 constexpr int KP = SV_DP;          // 160
@@ -63,7 +70,8 @@ constexpr int YIMG_BYTES = BY * KP * 2;        // 20480
 constexpr int TIMG_BYTES = KP * BY * 2;        // 20480
 constexpr int STAGE_BYTES = YIMG_BYTES + TIMG_BYTES;
 constexpr int NCHUNK = YIMG_BYTES / 16;        // 1280 chunks per image
-constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * 32 * 4;   // + per-wave rescale factors
+constexpr int NSTAGE = 3;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + 8 * 32 * 4;   // + per-wave rescale factors
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
@@ -140,19 +148,27 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     }
     const char* Yg = reinterpret_cast<const char*>(a.Y);
     const char* Tg = reinterpret_cast<const char*>(a.YT);
-#define SV_STAGE(t_, buf_)                                                                       \
-    {                                                                                            \
-        const char* yb_ = Yg + (size_t)(t_) * (BY * KP * 2);                                     \
-        const char* tb_ = Tg + (size_t)(t_) * (BY * 2);                                          \
-        char* ly_ = smem + (buf_) * STAGE_BYTES + wave * 1024;                                   \
-        glds16(yb_ + offY[0], ly_);                                                              \
-        glds16(yb_ + offY[1], ly_ + 8192);                                                       \
-        if (wave < 4) glds16(yb_ + offY[2], ly_ + 16384);                                        \
-        if (MODE != MODE_FWD) {                                                                  \
-            glds16(tb_ + offT[0], ly_ + YIMG_BYTES);                                             \
-            glds16(tb_ + offT[1], ly_ + YIMG_BYTES + 8192);                                      \
-            if (wave < 4) glds16(tb_ + offT[2], ly_ + YIMG_BYTES + 16384);                       \
-        }                                                                                        \
+    // One LDS-DMA piece = one wave-instruction = 1 KiB.  A tile has 20 (+20 for Y^T) pieces; wave w issues pieces
+    // w and w + 8 of each image, waves 0..3 also piece w + 16.  Piece q of wave w (q = 0..NPIECE-1) alternates
+    // between the two images.  Issued ONE AT A TIME between MFMAs: a burst of all 40 right after the barrier
+    // queued every wave behind the CU's address path for 700-1000 cycles per tile (measured).
+    constexpr int NIMG = MODE == MODE_FWD ? 1 : 2;
+    const int npiece = (wave < 4 ? 3 : 2) * NIMG;
+#define SV_PIECE(q_, ybase_, tbase_, lbase_)                                                            \
+    {                                                                                                  \
+        const int i_ = (q_) / NIMG;                                                                    \
+        if (NIMG == 1 || ((q_) & 1) == 0)                                                              \
+            glds16((ybase_) + offY[i_], (lbase_) + 8192 * i_);                                         \
+        else                                                                                           \
+            glds16((tbase_) + offT[i_], (lbase_) + YIMG_BYTES + 8192 * i_);                            \
+    }
+#define SV_STAGE_ALL(t_, buf_)                                                                          \
+    {                                                                                                  \
+        const char* yb_ = Yg + (size_t)(t_) * (BY * KP * 2);                                           \
+        const char* tb_ = Tg + (size_t)(t_) * (BY * 2);                                                \
+        char* ly_ = smem + (buf_) * STAGE_BYTES + wave * 1024;                                         \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3 * NIMG; ++q_)                                        \
+            if (q_ < npiece) SV_PIECE(q_, yb_, tb_, ly_)                                               \
     }
 
     // fragment read offsets inside a stage
@@ -161,16 +177,72 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     int rb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) rb[q] = YIMG_BYTES + li * (BY * 2) + 16 * ((2 * q + lh) ^ sw2);
-    float* fs = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES) + wave * 32;
+    float* fs = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES) + wave * 32;
 
-    if (t_begin < t_end) SV_STAGE(t_begin, 0)
+    // Three LDS stages; tile t lives in stage (t - t_begin) % 3.  An LDS-DMA piece takes 1-2 us from issue to
+    // landed under load (about one tile), so a tile's pieces are issued between one and two tiles ahead:
+    // pieces 0,1 of tile t+3 behind the barrier of tile t (into tile t's stage: every wave made its last read of
+    // it before that barrier), pieces 2.. of tile t+2 in the first half of tile t.
+    if (t_begin < t_end) SV_STAGE_ALL(t_begin, 0)
+    if (t_begin + 1 < t_end) SV_STAGE_ALL(t_begin + 1, 1)
+    if (t_begin + 2 < t_end) {
+        const char* yb_ = Yg + (size_t)(t_begin + 2) * (BY * KP * 2);
+        const char* tb_ = Tg + (size_t)(t_begin + 2) * (BY * 2);
+        char* ly_ = smem + 2 * STAGE_BYTES + wave * 1024;
+        if (MODE == MODE_FWD) {
+            SV_STAGE_ALL(t_begin + 2, 2)
+        } else {
+            SV_PIECE(0, yb_, tb_, ly_)
+            SV_PIECE(1, yb_, tb_, ly_)
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // Fragment reads run one phase ahead of the MFMAs that use them (an MFMA that waits for a read issued
+    // just before it exposes the whole LDS latency): GEMM1 of a sub-tile issues GEMM2's Y^T fragments,
+    // GEMM2 issues the next sub-tile's Y fragments.  One ds_read_b128 behind each MFMA.
+#define SV_YA(st_, sub_, s_) \
+    (*reinterpret_cast<const bf16x8*>((st_) + (sub_) * (32 * KP * 2) + 64 * ((s_) >> 1) + (((s_) & 1) ? ra1 : ra0)))
+#define SV_YB(st_, sub_, i_) \
+    (*reinterpret_cast<const bf16x8*>((st_) + ((i_) >> 1) * (32 * BY * 2) + rb[2 * (sub_) + ((i_) & 1)]))
+#define SV_PAIR                                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    bf16x8 fa[KS1], fb[KS1];
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) fa[s] = SV_YA(smem, 0, s);
+
+#ifdef SV_PROJ_TIMING
+    const unsigned long long blk_rt0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long blk_c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long ts_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ts_last = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    // Two waves share a SIMD (w and w + 4).  Running the same program from the same barrier they stay in
+    // lockstep: both in their exp/pack phase (matrix pipe idle), then both in an MFMA phase (measured: a third
+    // of the tile time).  So the two halves of the workgroup put the tile's barrier at different points of the
+    // SAME program -- waves 0..3 behind exp/pack of the second sub-tile, waves 4..7 in front of it: behind the
+    // barrier one half runs MFMAs while the other runs its VALU phase.  Both points satisfy the barrier's
+    // contract (own pieces of tile t+1 landed, last read of tile t's stage made).
+    auto main_loop = [&](auto early_tag) {
+    constexpr bool EARLY = decltype(early_tag)::value;
+    int bufi = 0;
     for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) SV_STAGE(t + 1, buf ^ 1)
-        const char* st = smem + buf * STAGE_BYTES;
+        const char* st = smem + bufi * STAGE_BYTES;
+        const int bufn = bufi == 2 ? 0 : bufi + 1;          // stage of tile t+1
+        const int bufp = bufi == 0 ? 2 : bufi - 1;          // stage of tile t-1 = stage of tile t+2
+        const char* stn = smem + bufn * STAGE_BYTES;
+        // this iteration's DMA (see above): the rest of tile t+2 into the stage tile t-1 left, then the first
+        // pieces of tile t+3 into tile t's own stage once the barrier is behind us
+        const bool dma2 = t + 2 < t_end, dma3 = t + 3 < t_end;
+        const char* dy2 = Yg + (size_t)(t + 2) * (BY * KP * 2);
+        const char* dt2 = Tg + (size_t)(t + 2) * (BY * 2);
+        char* dl2 = smem + bufp * STAGE_BYTES + wave * 1024;
+        char* dl3 = smem + bufi * STAGE_BYTES + wave * 1024;
+#define SV_DMA2(q_) if (dma2 && (q_) < npiece) SV_PIECE(q_, dy2, dt2, dl2)
+#define SV_DMA3(q_) if (dma3 && (q_) < npiece) SV_PIECE(q_, dy2 + BY * KP * 2, dt2 + BY * 2, dl3)
 
         // accumulator rows of a 32x32 tile: y = (r&3) + 8*(r>>2) + 4*lh  -> groups of 4 consecutive y
 #pragma unroll
@@ -180,16 +252,42 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
             for (int r = 0; r < 16; ++r) c1[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < KS1; ++s) {
-                const bf16x8 ya = *reinterpret_cast<const bf16x8*>(st + sub * (32 * KP * 2) + 64 * (s >> 1) + ((s & 1) ? ra1 : ra0));
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xf[s], c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], xf[s], c1, 0, 0, 0);
+                if (MODE != MODE_FWD) {
+                    fb[s] = SV_YB(st, sub, s);
+                    SV_PAIR
+                    if (sub == 0 && s == 2) SV_DMA2(2)
+                    if (sub == 0 && s == 6) SV_DMA2(3)
+                } else {
+                    // no GEMM2: fetch the next sub-tile's Y fragments here (the next tile's stage is complete:
+                    // FWD puts its barrier in the middle of the tile, see below)
+                    fa[s] = sub == 0 ? SV_YA(st, 1, s) : SV_YA(stn, 0, s);
+                    SV_PAIR
+                    if (sub == 1 && (s == 1 || s == 4 || s == 7)) SV_DMA3(s / 3)
+                }
+            }
+            SV_TS(0)
+            if (EARLY && sub == (MODE == MODE_FWD ? 0 : 1)) {
+                // The one barrier of the tile.  Behind it tile t+1 has landed everywhere (each wave waits for its
+                // own pieces of it; its pieces of tile t+2 stay in flight) and every wave has made its last read
+                // of tile t's stage.
+                if (!dma2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NIMG) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIMG) : "memory");
+                SV_TS(4)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                SV_TS(5)
             }
             if (MODE != MODE_DW) {
                 float tm = fmaxf(c1[0], c1[1]);
 #pragma unroll
                 for (int r = 2; r < 16; r += 2) tm = fmaxf(tm, fmaxf(c1[r], c1[r + 1]));
-                tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-                const bool need = tm > thr;
-                if (__any(need)) {
+                // (the two lane halves of a row are only reconciled inside the rare branch)
+                if (__any(tm > thr)) {
+                    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+                    const bool need = tm > thr;
                     // raise the stabiliser of the rows that need it; the value used is the one the bf16 hi/lo pair
                     // represents exactly, so the MFMA and the bookkeeping agree
                     const float mn = fmaxf(m_eff + tm, -1.0e4f);
@@ -227,13 +325,13 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(c1[r]);
+            bf16x8 pa[2];
             if (MODE == MODE_FWD) {
                 float acc = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc += p[r];
                 l_run += acc;
             } else {
-                bf16x8 pa[2];
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     uint4 u;
@@ -243,23 +341,62 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                     u.w = pack_bf16(p[8 * s2 + 6], p[8 * s2 + 7]);
                     pa[s2] = *reinterpret_cast<bf16x8*>(&u);
                 }
+            }
+            SV_TS(1)
+            if (!EARLY && sub == (MODE == MODE_FWD ? 0 : 1)) {
+                // The one barrier of the tile.  Behind it tile t+1 has landed everywhere (each wave waits for its
+                // own pieces of it; its pieces of tile t+2 stay in flight) and every wave has made its last read
+                // of tile t's stage.
+                if (!dma2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NIMG) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIMG) : "memory");
+                SV_TS(4)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                SV_TS(5)
+            }
+            if (MODE != MODE_FWD) {
                 // GEMM2: Z[x][n] += sum_y P[y][x] Y[y][n].  k-order of a converted accumulator: element j of
                 // half lh is y = 16 s2 + 8 (j>>2) + 4 lh + (j&3); the Y^T copy stores its columns in that order
                 // (proj_prep), so a fragment is one 16-byte read.
 #pragma unroll
-                for (int n = 0; n < NT2; ++n) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(st + n * (32 * BY * 2) + rb[2 * sub + s2]);
-                        Z[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2], yb, Z[n], 0, 0, 0);
-                    }
+                for (int i = 0; i < KS1; ++i) {
+                    Z[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i & 1], fb[i], Z[i >> 1], 0, 0, 0);
+                    fa[i] = sub == 0 ? SV_YA(st, 1, i) : SV_YA(stn, 0, i);
+                    SV_PAIR
+                    if (sub == 0 && i == 2) SV_DMA2(4)
+                    if (sub == 0 && i == 6) SV_DMA2(5)
+                    if (sub == 1 && i == 2) SV_DMA3(0)
+                    if (sub == 1 && i == 6) SV_DMA3(1)
                 }
+                SV_TS(3)
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        bufi = bufn;
     }
-#undef SV_STAGE
+    };
+    if (wave < 4) main_loop(std::false_type{});
+    else main_loop(std::true_type{});
+#undef SV_DMA2
+#undef SV_DMA3
+#ifdef SV_PROJ_TIMING
+    if (lane == 0 && wave == 0 && blockIdx.x < 4096) {
+        g_proj_blk[MODE][blockIdx.x][0] = blk_rt0;
+        g_proj_blk[MODE][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        g_proj_blk[MODE][blockIdx.x][2] = __builtin_amdgcn_s_memtime() - blk_c0;
+        g_proj_blk[MODE][blockIdx.x][3] = (unsigned long long)(t_end - t_begin);
+    }
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {
+        for (int i = 0; i < 6; ++i) g_proj_dbg[MODE][wave >> 2][i] = ts_acc[i];
+        g_proj_dbg[MODE][wave >> 2][7] = (unsigned long long)(t_end - t_begin);
+    }
+#endif
+#undef SV_YA
+#undef SV_YB
+#undef SV_PAIR
+#undef SV_STAGE_ALL
+#undef SV_PIECE
 
     const bool any_tile = t_begin < t_end;
     if (MODE == MODE_FWD) {
@@ -524,6 +661,14 @@ int launch_proj(ProjArgs a, hipStream_t st) {
 
 }  // namespace
 
+#ifdef SV_PROJ_TIMING
+extern "C" int svae_debug_proj(unsigned long long* out48) {
+    return (int)hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_proj_dbg), 48 * sizeof(unsigned long long));
+}
+extern "C" int svae_debug_proj_blocks(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_proj_blk), 3 * 4096 * 4 * sizeof(unsigned long long));
+}
+#endif
 extern "C" int svae_proj_nsplit(void) { return NSPLIT; }
 extern "C" int svae_proj_tile(void) { return BY; }
 

@@ -114,6 +114,7 @@ class SVAEEngine:
             self.ws["pslabs"] = torch.empty(8 * capp * DP, **f32)
             self.ws["pslabs_side"] = torch.empty(8 * self.IPAD * DP, **f32)
             if self.w3b is None:
+                self.mlp_frags = torch.zeros(_lib.load().svae_mlp_frag_elems(), **bf)
                 self.w3b = torch.zeros(self.IPAD * DP, **bf)
                 self.w3s = torch.zeros(self.IPAD * DP, **bf)
                 self.w3tb = torch.zeros(DP * self.IPAD, **bf)
@@ -193,10 +194,6 @@ class SVAEEngine:
                   self.P("gru.bias_hh_l0").data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(),
                   plan.B, plan.Tmax, w["hs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(), self.gru_prec, st)
         self._toc("gru_fwd", ev)
-        self._gemm(w["hs"], self.P("encoder.linear1.weight"), w["enc"], R, DP, HP, HP, HP, DP, 0, 0,
-                   bias=self.P("encoder.linear1.bias"), act=1)
-        self._gemm(w["enc"], self.P("linear1.weight"), w["tmp"], R, 2 * L, DP, DP, DP, 2 * L, 0, 0,
-                   bias=self.P("linear1.bias"))
         if eps is not None:
             if eps.numel() != R * L:
                 raise ValueError("eps must have %d x %d elements" % (R, L))
@@ -204,10 +201,25 @@ class SVAEEngine:
         else:
             _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
                       int(step) & 0xFFFFFFFF, st)
-        _lib.call("svae_latent_fwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["z"].data_ptr(),
-                  w["kl_row"].data_ptr(), R, st)
-        self._gemm(w["z"], self.P("decoder.linear1.weight"), w["d1"], R, DP, L, L, L, DP, 0, 0,
-                   bias=self.P("decoder.linear1.bias"), act=1)
+        if self.fused:
+            # encoder -> (mu | log_sigma) -> z, KL -> decoder hidden in one kernel (bf16 MFMA mode)
+            _lib.call("svae_mlp_prep", self.P("encoder.linear1.weight").data_ptr(), self.P("linear1.weight").data_ptr(),
+                      self.P("decoder.linear1.weight").data_ptr(), self.mlp_frags.data_ptr(), st)
+            ev = self._tic("mlp_fwd")
+            _lib.call("svae_mlp_fwd", w["hs"].data_ptr(), w["eps"].data_ptr(), self.mlp_frags.data_ptr(),
+                      self.P("encoder.linear1.bias").data_ptr(), self.P("linear1.bias").data_ptr(),
+                      self.P("decoder.linear1.bias").data_ptr(), w["enc"].data_ptr(), w["tmp"].data_ptr(),
+                      w["z"].data_ptr(), w["d1"].data_ptr(), w["kl_row"].data_ptr(), R, st)
+            self._toc("mlp_fwd", ev)
+        else:
+            self._gemm(w["hs"], self.P("encoder.linear1.weight"), w["enc"], R, DP, HP, HP, HP, DP, 0, 0,
+                       bias=self.P("encoder.linear1.bias"), act=1)
+            self._gemm(w["enc"], self.P("linear1.weight"), w["tmp"], R, 2 * L, DP, DP, DP, 2 * L, 0, 0,
+                       bias=self.P("linear1.bias"))
+            _lib.call("svae_latent_fwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["z"].data_ptr(),
+                      w["kl_row"].data_ptr(), R, st)
+            self._gemm(w["z"], self.P("decoder.linear1.weight"), w["d1"], R, DP, L, L, L, DP, 0, 0,
+                       bias=self.P("decoder.linear1.bias"), act=1)
         if self.fused and want_loss:
             self._last_fused = True
             self._proj_prepare(R)
@@ -325,14 +337,21 @@ class SVAEEngine:
             self._gemm(dl, self.P("decoder.linear2.weight"), w["dd1"], R, DP, IP, IP, DP, DP, 0, 1,
                        act=2, aux=w["d1"], ldaux=DP, tag="proj_dx")
         # data-gradient chain: decoder.linear1 -> latent -> linear1 -> encoder.linear1
-        self._gemm(w["dd1"], self.P("decoder.linear1.weight"), w["dz"], R, L, DP, DP, L, L, 0, 1)
-        _lib.call("svae_latent_bwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["dz"].data_ptr(),
-                  plan.w_kl.data_ptr(), float(anneal), w["dtmp"].data_ptr(), R, st)
-        if self._dtmp_extra is not None:          # dense surface: dL/dmu, dL/dlog_sigma arriving from VAELoss
-            w["dtmp"][:R * 2 * L].add_(self._dtmp_extra.reshape(-1))
-        self._gemm(w["dtmp"], self.P("linear1.weight"), w["denc"], R, DP, 2 * L, 2 * L, DP, DP, 0, 1,
-                   act=2, aux=w["enc"], ldaux=DP)
-        self._gemm(w["denc"], self.P("encoder.linear1.weight"), w["dhs"], R, HP, DP, DP, HP, HP, 0, 1)
+        if self.fused and self._dtmp_extra is None:
+            ev = self._tic("mlp_bwd")
+            _lib.call("svae_mlp_bwd", w["dd1"].data_ptr(), w["tmp"].data_ptr(), w["eps"].data_ptr(),
+                      w["enc"].data_ptr(), plan.w_kl.data_ptr(), self.mlp_frags.data_ptr(), float(anneal),
+                      w["dtmp"].data_ptr(), w["denc"].data_ptr(), w["dhs"].data_ptr(), R, st)
+            self._toc("mlp_bwd", ev)
+        else:
+            self._gemm(w["dd1"], self.P("decoder.linear1.weight"), w["dz"], R, L, DP, DP, L, L, 0, 1)
+            _lib.call("svae_latent_bwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["dz"].data_ptr(),
+                      plan.w_kl.data_ptr(), float(anneal), w["dtmp"].data_ptr(), R, st)
+            if self._dtmp_extra is not None:          # dense surface: dL/dmu, dL/dlog_sigma arriving from VAELoss
+                w["dtmp"][:R * 2 * L].add_(self._dtmp_extra.reshape(-1))
+            self._gemm(w["dtmp"], self.P("linear1.weight"), w["denc"], R, DP, 2 * L, 2 * L, DP, DP, 0, 1,
+                       act=2, aux=w["enc"], ldaux=DP)
+            self._gemm(w["denc"], self.P("encoder.linear1.weight"), w["dhs"], R, HP, DP, DP, HP, HP, 0, 1)
 
         def decoder_side_wgrads(slabs):
             self._wgrad(w["dd1"], w["z"], "decoder.linear1.weight", R, DP, L, DP, L, slabs=slabs)
