@@ -48,10 +48,12 @@ int svae_reduce_slabs(const float* slabs, float* out, long long n, int nsplit, l
  * svae_embed_fwd replaces self.item_embed(x) nb:756: out[r][:] = table[x[r]][:] (E = 256).
  * svae_embed_bwd replaces the embedding backward of loss.backward() nb:1205 as a deterministic
  * segmented sum: perm = rows sorted by item, segment s covers perm[seg_off[s]..seg_off[s+1]) and is
- * written to gtable[seg_item[s]] (gtable zero-filled by the caller). */
+ * written to gtable[seg_item[s]] (gtable zero-filled by the caller).  Segments are ordered by length,
+ * longest first; the first nlong of them have more than svae_embed_long_rows() rows (a workgroup each). */
 int svae_embed_fwd(const float* table, const int* x, float* out, int R, int I, void* stream);
+int svae_embed_long_rows(void);
 int svae_embed_bwd(const float* demb, const int* perm, const int* seg_off, const int* seg_item, float* gtable,
-                   int nseg, float scale, void* stream);
+                   int nseg, int nlong, float scale, void* stream);
 
 /* ---- GRU recurrence, persistent over timesteps ---------------------------------------------------
  * svae_gru_fwd replaces the recurrent part of nn.GRU (call nb:759, definition nb:724-727; h0 = 0).
@@ -109,7 +111,9 @@ int svae_loss_reduce(const float* nll_row, const float* kl_row, const float* w_n
  *                         dd1 [R][160] = dL/d(pre-tanh decoder hidden); writes the row constants into h2b.
  *                         slabs = 8 R 160 floats, mpart = 8 R floats of scratch
  *   svae_proj_nll_bwd_dw  weight-side gradient gw3 [I_rows][160], gb3 [I_rows] (after _fwd_dh of the same
- *                         batch); slabs = 8 I 160 floats; occ_off [I+1] / occ_row = target occurrences by item
+ *                         batch); slabs = 8 I 160 floats; occ_off [I+1] / occ_row = target occurrences by item,
+ *                         occ_items [I] = items by occurrence count (descending), the first nocc_long of them
+ *                         with more than svae_proj_occ_long() occurrences
  * R_pad, I_pad: multiples of 64.  parts (bit mask, 3 = everything): 1 sweep kernel, 2 finish kernel -- the
  * split exists so a profiler can bracket one kernel. */
 int svae_proj_nsplit(void);
@@ -123,9 +127,11 @@ int svae_proj_nll_fwd_dh(const void* h2s, void* h2b, const void* w3b, const void
                          const float* w3, const float* b3, const int* tgt, const float* w_nll, int R, int I, int K,
                          float* slabs, float* mpart, float* nll_row, float* lse, float* dd1, int parts,
                          void* stream);
+int svae_proj_occ_long(void);
 int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad, int I, int I_rows,
-                         const float* h2, const float* w_nll, const int* occ_off, const int* occ_row, float* slabs,
-                         float* gw3, float* gb3, int parts, void* stream);
+                         const float* h2, const float* w_nll, const int* occ_off, const int* occ_row,
+                         const int* occ_items, int nocc_long, float* slabs, float* gw3, float* gb3, int parts,
+                         void* stream);
 
 /* ---- Adam with L2 weight decay on one flat buffer ----------------------------------------------------
  * Replaces optimizer.step() nb:1206 with torch.optim.Adam(weight_decay=5e-3) nb:1260-1263 (and the

@@ -24,7 +24,9 @@ SIGNATURES = {
     "svae_gru_fwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
     "svae_gru_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "svae_embed_fwd": [_P, _P, _P, _I, _I, _P],
-    "svae_embed_bwd": [_P, _P, _P, _P, _P, _I, _F, _P],
+    "svae_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "svae_embed_long_rows": [],
+    "svae_proj_occ_long": [],
     "svae_latent_fwd": [_P, _P, _P, _P, _I, _P],
     "svae_latent_bwd": [_P, _P, _P, _P, _F, _P, _I, _P],
     "svae_softmax_nll": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -39,7 +41,7 @@ SIGNATURES = {
     "svae_proj_prep_items": [_P, _P, _I, _I, _P, _P, _P, _P],
     "svae_proj_nll_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "svae_proj_nll_fwd_dh": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
-    "svae_proj_nll_bwd_dw": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "svae_proj_nll_bwd_dw": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P],
     "svae_mlp_frag_elems": [],
     "svae_mlp_prep": [_P, _P, _P, _P, _P],
     "svae_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],

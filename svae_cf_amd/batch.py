@@ -16,17 +16,21 @@ nb:509-513).  Here a batch of B users is packed TIME-MAJOR:
 import numpy as np
 import torch
 
+EMBED_LONG_ROWS = 16     # = svae_embed_long_rows(): longer item segments get a whole workgroup in svae_embed_bwd
+OCC_LONG = 32            # = svae_proj_occ_long(): same for an item's target occurrences in svae_proj_nll_bwd_dw
+
 
 class BatchPlan:
     """Device-resident description of one batch (all int32 / fp32 tensors)."""
 
     __slots__ = ("B", "R", "Tmax", "K", "order", "lengths", "x", "tgt", "w_nll", "w_kl", "row_off",
                  "nact", "last_row", "perm", "seg_off", "seg_item", "nseg", "row_key", "seen",
-                 "seen_off", "row_of", "device", "occ_off", "occ_row", "total_items")
+                 "seen_off", "row_of", "device", "occ_off", "occ_row", "total_items", "nseg_long", "occ_items",
+                 "nocc_long")
 
     def to(self, device):
         for name in ("x", "tgt", "w_nll", "w_kl", "row_off", "nact", "last_row", "perm", "seg_off",
-                     "seg_item", "row_key", "seen", "seen_off", "occ_off", "occ_row"):
+                     "seg_item", "row_key", "seen", "seen_off", "occ_off", "occ_row", "occ_items"):
             v = getattr(self, name)
             if v is not None:
                 setattr(self, name, v.to(device, non_blocking=True))
@@ -94,17 +98,25 @@ def build_plan(users, next_k, user_keys=None, device=None, pin=False, total_item
         num_ones = float(n_r[row_of[u][0]])          # first timestep's target count (nb:803)
         w_nll[row_of[u]] = 1.0 / (B * num_ones)
     # rows sorted by item for the deterministic embedding scatter-add
-    perm = np.argsort(x, kind="stable").astype(np.int32)
+    # (segments ordered by length, longest first: the kernel gives the long ones a workgroup each)
+    perm = np.argsort(x, kind="stable")
     xs = x[perm]
     starts = np.flatnonzero(np.concatenate(([True], xs[1:] != xs[:-1])))
-    seg_item = xs[starts].astype(np.int32)
-    seg_off = np.concatenate((starts, [R])).astype(np.int32)
+    seg_len = np.diff(np.concatenate((starts, [R])))
+    by_len = np.argsort(-seg_len, kind="stable")
+    seg_len = seg_len[by_len]
+    seg_item = xs[starts[by_len]].astype(np.int32)
+    seg_off = np.zeros(len(by_len) + 1, dtype=np.int32)
+    np.cumsum(seg_len, out=seg_off[1:])
+    perm = perm[np.repeat(starts[by_len] - seg_off[:-1], seg_len) + np.arange(R)].astype(np.int32)
+    nseg_long = int((seg_len > EMBED_LONG_ROWS).sum())
 
     p = BatchPlan()
     p.B, p.R, p.Tmax, p.K = B, R, Tmax, K
     p.order = order
     p.lengths = T
     p.nseg = int(len(seg_item))
+    p.nseg_long = nseg_long
     p.row_of = row_of
     p.device = None
 
@@ -116,7 +128,8 @@ def build_plan(users, next_k, user_keys=None, device=None, pin=False, total_item
     p.perm, p.seg_off, p.seg_item = t(perm), t(seg_off), t(seg_item)
     p.row_key, p.seen, p.seen_off = t(row_key), t(seen), t(seen_off)
     p.total_items = total_items
-    p.occ_off = p.occ_row = None
+    p.occ_off = p.occ_row = p.occ_items = None
+    p.nocc_long = 0
     if total_items is not None:
         rr, kk = np.nonzero(tgt >= 0)
         it = tgt[rr, kk]
@@ -124,6 +137,9 @@ def build_plan(users, next_k, user_keys=None, device=None, pin=False, total_item
         occ_off = np.zeros(total_items + 1, dtype=np.int32)
         np.cumsum(np.bincount(it, minlength=total_items), out=occ_off[1:])
         p.occ_off, p.occ_row = t(occ_off), t(rr[o].astype(np.int32))
+        cnt = np.diff(occ_off)
+        occ_items = np.argsort(-cnt, kind="stable").astype(np.int32)      # items by occurrence count, busiest first
+        p.occ_items, p.nocc_long = t(occ_items), int((cnt > OCC_LONG).sum())
     if device is not None:
         p.to(device)
     return p

@@ -22,21 +22,58 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, const int* __r
     }
 }
 
-// Deterministic scatter-add: rows are pre-sorted by item on the host (perm), one wave sums the rows
-// of one item in a fixed order and stores the result -- no atomics, bitwise reproducible.
+// Deterministic scatter-add: rows are pre-sorted by item on the host (perm), the rows of one item are summed
+// in a fixed order and stored -- no atomics, bitwise reproducible.  Item popularity is heavily skewed (a
+// popular item is in every user's history), so segments come sorted by length: the first `nlong` (more
+// than EMB_LONG rows) get a whole workgroup each, the rest one wave each; both keep 4 rows in flight per
+// wave (one wave walking a 256-row segment one dependent load at a time was the kernel's whole run time).
+constexpr int EMB_LONG = 16;
+
+__device__ __forceinline__ float4 embed_seg_sum(const float* __restrict__ demb, const int* __restrict__ perm, int b,
+                                                int e, int first, int step, int lane) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = b + first; i < e; i += 4 * step) {
+        int r[4];
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = (i + j * step < e) ? perm[i + j * step] : -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const float4*>(demb + (size_t)(r[j] < 0 ? 0 : r[j]) * SV_E)[lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r[j] >= 0) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_long_kernel(const float* __restrict__ demb, const int* __restrict__ perm,
+                                                             const int* __restrict__ seg_off,
+                                                             const int* __restrict__ seg_item,
+                                                             float* __restrict__ gtable, float scale) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x;
+    red[wave][lane] = embed_seg_sum(demb, perm, seg_off[s], seg_off[s + 1], wave, 4, lane);
+    __syncthreads();
+    if (wave != 0) return;
+    float4 acc = red[0][lane];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        const float4 u = red[q][lane];
+        acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+    }
+    acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+    reinterpret_cast<float4*>(gtable + (size_t)seg_item[s] * SV_E)[lane] = acc;
+}
+
 __global__ void embed_bwd_kernel(const float* __restrict__ demb, const int* __restrict__ perm,
                                  const int* __restrict__ seg_off, const int* __restrict__ seg_item,
-                                 float* __restrict__ gtable, int nseg, float scale) {
+                                 float* __restrict__ gtable, int first, int nseg, float scale) {
     const int lane = threadIdx.x & 63;
-    int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int s = first + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int stride = gridDim.x * (blockDim.x >> 6);
     for (; s < nseg; s += stride) {
-        const int b = seg_off[s], e = seg_off[s + 1];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = b; i < e; ++i) {
-            const float4 v = reinterpret_cast<const float4*>(demb + (size_t)perm[i] * SV_E)[lane];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
+        float4 acc = embed_seg_sum(demb, perm, seg_off[s], seg_off[s + 1], 0, 1, lane);
         acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
         reinterpret_cast<float4*>(gtable + (size_t)seg_item[s] * SV_E)[lane] = acc;
     }
@@ -359,12 +396,19 @@ extern "C" int svae_embed_fwd(const float* table, const int* x, float* out, int 
 }
 
 // Reference interface replaced: embedding backward inside loss.backward() (nb:1205).  gtable must be
-// zero-filled by the caller; only rows of items present in the batch are written.
+// zero-filled by the caller; only rows of items present in the batch are written.  Segments are sorted by
+// length (descending); the first nlong of them are the ones longer than svae_embed_long_rows().
+extern "C" int svae_embed_long_rows(void) { return EMB_LONG; }
 extern "C" int svae_embed_bwd(const float* demb, const int* perm, const int* seg_off, const int* seg_item,
-                              float* gtable, int nseg, float scale, void* stream) {
-    SV_CHECK_ARG(demb && perm && seg_off && seg_item && gtable && nseg > 0, "svae_embed_bwd: bad arguments");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(wave_rows_grid(nseg)), dim3(256), 0, (hipStream_t)stream, demb, perm,
-                       seg_off, seg_item, gtable, nseg, scale);
+                              float* gtable, int nseg, int nlong, float scale, void* stream) {
+    SV_CHECK_ARG(demb && perm && seg_off && seg_item && gtable && nseg > 0 && nlong >= 0 && nlong <= nseg,
+                 "svae_embed_bwd: bad arguments");
+    if (nlong > 0)
+        hipLaunchKernelGGL(embed_bwd_long_kernel, dim3(nlong), dim3(256), 0, (hipStream_t)stream, demb, perm, seg_off,
+                           seg_item, gtable, scale);
+    if (nseg > nlong)
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3(wave_rows_grid(nseg - nlong)), dim3(256), 0, (hipStream_t)stream, demb,
+                           perm, seg_off, seg_item, gtable, nlong, nseg, scale);
     SV_LAUNCH_CHECK();
     return 0;
 }

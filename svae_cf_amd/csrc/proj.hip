@@ -220,14 +220,9 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     unsigned long long ts_last = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-    // Two waves share a SIMD (w and w + 4).  Running the same program from the same barrier they stay in
-    // lockstep: both in their exp/pack phase (matrix pipe idle), then both in an MFMA phase (measured: a third
-    // of the tile time).  So the two halves of the workgroup put the tile's barrier at different points of the
-    // SAME program -- waves 0..3 behind exp/pack of the second sub-tile, waves 4..7 in front of it: behind the
-    // barrier one half runs MFMAs while the other runs its VALU phase.  Both points satisfy the barrier's
-    // contract (own pieces of tile t+1 landed, last read of tile t's stage made).
-    auto main_loop = [&](auto early_tag) {
-    constexpr bool EARLY = decltype(early_tag)::value;
+    // (Tried and dropped: putting the tile's barrier at different points of the program for waves 0..3 and
+    //  4..7 so the two waves of a SIMD do not run their exp/pack phases together -- no gain, measured.)
+    constexpr bool EARLY = false;
     int bufi = 0;
     for (int t = t_begin; t < t_end; ++t) {
         const char* st = smem + bufi * STAGE_BYTES;
@@ -375,9 +370,6 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
         }
         bufi = bufn;
     }
-    };
-    if (wave < 4) main_loop(std::false_type{});
-    else main_loop(std::true_type{});
 #undef SV_DMA2
 #undef SV_DMA3
 #ifdef SV_PROJ_TIMING
@@ -575,72 +567,114 @@ __global__ void proj_fdh_finish_kernel(const float* __restrict__ slabs, const fl
     }
 }
 
-// dL/dW3, dL/db3 finish: one workgroup per item.  Wave 0 sums the slabs; the item's target occurrences
-// (pairs sorted by item on the host: occ_row lists the data rows) are split over the 4 waves, 4 in flight
-// per wave, and their partial sums are added in a fixed order (bitwise reproducible).  Column 150 of the
-// slab sum is the bias gradient (ones column), its target part is -sum w_r.
-__global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __restrict__ slabs,
-                                                             const float* __restrict__ h2,
-                                                             const float* __restrict__ w_nll,
-                                                             const int* __restrict__ occ_off,
-                                                             const int* __restrict__ occ_row, float* __restrict__ gw3,
-                                                             float* __restrict__ gb3, int I, int I_pad) {
-    __shared__ float4 red[4][KP / 4];
-    __shared__ float wred[4];
+// dL/dW3, dL/db3 finish.  Per item: sum the NSPLIT slabs, subtract the target part sum_r w_r h2[r] over the
+// item's target occurrences (pairs sorted by item on the host: occ_row lists the data rows), write the row.
+// Column 150 of the slab sum is the bias gradient (ones column), its target part is -sum w_r.
+// Occurrence counts are heavily skewed, so the host lists the items by count (occ_items): the first `nlong`
+// (more than OCC_LONG occurrences) get a workgroup each -- occurrences split over the 4 waves, 4 in flight per
+// wave, partial sums added in a fixed order (bitwise reproducible) -- the others one wave each.
+constexpr int OCC_LONG = 32;
+
+__device__ __forceinline__ void dw_occ_sum(const float* __restrict__ h2, const float* __restrict__ w_nll,
+                                           const int* __restrict__ occ_row, int b, int e, int first, int step, int ln,
+                                           float4& s, float& wsum) {
+    for (int o = b + first; o < e; o += 4 * step) {
+        int r[4];
+        float w[4];
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = (o + j * step < e) ? occ_row[o + j * step] : -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = r[j] < 0 ? 0 : r[j];
+            w[j] = r[j] < 0 ? 0.f : w_nll[rr];
+            v[j] = reinterpret_cast<const float4*>(h2 + (size_t)rr * KP)[ln];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s.x -= w[j] * v[j].x; s.y -= w[j] * v[j].y; s.z -= w[j] * v[j].z; s.w -= w[j] * v[j].w;
+            wsum += w[j];
+        }
+    }
+}
+
+__device__ __forceinline__ void dw_write_row(float4 t, float wsum, int it, int lane, float* __restrict__ gw3,
+                                             float* __restrict__ gb3) {
+    if (lane == SV_D / 4) {          // lane 37 holds columns 148..151: column 150 = bias gradient
+        gb3[it] = t.z - wsum;
+        t.z = 0.f;
+    }
+    const int c0 = 4 * lane;
+    if (c0 + 0 >= SV_D) t.x = 0.f;
+    if (c0 + 1 >= SV_D) t.y = 0.f;
+    if (c0 + 2 >= SV_D) t.z = 0.f;
+    if (c0 + 3 >= SV_D) t.w = 0.f;
+    reinterpret_cast<float4*>(gw3 + (size_t)it * KP)[lane] = t;
+}
+
+constexpr int DWL_WAVES = 16;   // the busiest item has ~ k * B occurrences: 16 waves x 4 in flight walk it in ~16 rounds
+__global__ __launch_bounds__(64 * DWL_WAVES) void proj_dw_finish_long_kernel(const float* __restrict__ slabs,
+                                                                  const float* __restrict__ h2,
+                                                                  const float* __restrict__ w_nll,
+                                                                  const int* __restrict__ occ_off,
+                                                                  const int* __restrict__ occ_row,
+                                                                  const int* __restrict__ occ_items,
+                                                                  float* __restrict__ gw3, float* __restrict__ gb3, int I) {
+    __shared__ float4 red[DWL_WAVES][KP / 4];
+    __shared__ float wred[DWL_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int it = blockIdx.x;
+    const int it = occ_items[blockIdx.x];
     const int ln = lane < KP / 4 ? lane : 0;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float wsum = 0.f;
-    if (it < I) {
-        if (wave == 0) {
-            for (int z = 0; z < NSPLIT; ++z) {
-                const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * I + it) * KP)[ln];
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-        }
-        const int b = occ_off[it], e = occ_off[it + 1];
-        for (int o = b + wave; o < e; o += 16) {
-            int r[4];
-            float w[4];
-            float4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = (o + 4 * j < e) ? occ_row[o + 4 * j] : -1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rr = r[j] < 0 ? 0 : r[j];
-                w[j] = r[j] < 0 ? 0.f : w_nll[rr];
-                v[j] = reinterpret_cast<const float4*>(h2 + (size_t)rr * KP)[ln];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s.x -= w[j] * v[j].x; s.y -= w[j] * v[j].y; s.z -= w[j] * v[j].z; s.w -= w[j] * v[j].w;
-                wsum += w[j];
-            }
+    if (wave == 0) {
+        for (int z = 0; z < NSPLIT; ++z) {
+            const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * I + it) * KP)[ln];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
+    dw_occ_sum(h2, w_nll, occ_row, occ_off[it], occ_off[it + 1], wave, DWL_WAVES, ln, s, wsum);
     if (lane < KP / 4) red[wave][lane] = s;
     if (lane == 0) wred[wave] = wsum;
     __syncthreads();
     if (wave != 0 || lane >= KP / 4) return;
     float4 t = red[0][lane];
+    float wt = wred[0];
 #pragma unroll
-    for (int q = 1; q < 4; ++q) {
+    for (int q = 1; q < DWL_WAVES; ++q) {
         const float4 u = red[q][lane];
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        wt += wred[q];
     }
-    if (it < I) {
-        if (lane == SV_D / 4) {          // lane 37 holds columns 148..151: column 150 = bias gradient
-            gb3[it] = t.z - (wred[0] + wred[1] + wred[2] + wred[3]);
-            t.z = 0.f;
-        }
-        const int c0 = 4 * lane;
-        if (c0 + 0 >= SV_D) t.x = 0.f;
-        if (c0 + 1 >= SV_D) t.y = 0.f;
-        if (c0 + 2 >= SV_D) t.z = 0.f;
-        if (c0 + 3 >= SV_D) t.w = 0.f;
+    dw_write_row(t, wt, it, lane, gw3, gb3);
+}
+
+// one wave per entry j of [nlong, I_rows): entries below I are items (occ_items[j]), the rest pad rows (zeroed)
+__global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __restrict__ slabs,
+                                                             const float* __restrict__ h2,
+                                                             const float* __restrict__ w_nll,
+                                                             const int* __restrict__ occ_off,
+                                                             const int* __restrict__ occ_row,
+                                                             const int* __restrict__ occ_items, float* __restrict__ gw3,
+                                                             float* __restrict__ gb3, int nlong, int I, int I_rows) {
+    const int lane = threadIdx.x & 63;
+    const int j = nlong + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= I_rows || lane >= KP / 4) return;
+    if (j >= I) {
+        reinterpret_cast<float4*>(gw3 + (size_t)j * KP)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) gb3[j] = 0.f;
+        return;
     }
-    reinterpret_cast<float4*>(gw3 + (size_t)it * KP)[lane] = t;
+    const int it = occ_items[j];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wsum = 0.f;
+#pragma unroll
+    for (int z = 0; z < NSPLIT; ++z) {
+        const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * I + it) * KP)[lane];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    dw_occ_sum(h2, w_nll, occ_row, occ_off[it], occ_off[it + 1], 0, 1, lane, s, wsum);
+    dw_write_row(s, wsum, it, lane, gw3, gb3);
 }
 
 template <int MODE>
@@ -671,6 +705,7 @@ extern "C" int svae_debug_proj_blocks(unsigned long long* out) {
 #endif
 extern "C" int svae_proj_nsplit(void) { return NSPLIT; }
 extern "C" int svae_proj_tile(void) { return BY; }
+extern "C" int svae_proj_occ_long(void) { return OCC_LONG; }
 
 // bf16 operand copies of the decoder hidden rows (fp32 h2 [R][160], the tanh output of Decoder.linear1 nb:709):
 // h2b [R_pad][160] plain, h2s [R_pad][160] scaled by log2(e), h2tb [160][R_pad] transposed; R_pad % 64 == 0.
@@ -737,14 +772,16 @@ extern "C" int svae_proj_nll_fwd_dh(const void* h2s, void* h2b, const void* w3b,
 
 // Reference interface replaced: the weight-side half of the autograd of the same (nb:1205): gw3 [I_pad][160],
 // gb3 [I_pad].  Needs svae_proj_nll_fwd_dh of the same batch before it (row constants in h2b).
-// slabs: scratch of 8 * I * 160 floats.  occ_off [I+1] / occ_row: target occurrences by item.
+// slabs: scratch of 8 * I * 160 floats.  occ_off [I+1] / occ_row: target occurrences by item; occ_items [I]: the
+// items ordered by occurrence count (descending), the first nocc_long of them having more than svae_proj_occ_long().
 // I_rows >= I: rows of gw3 / gb3 (rows >= I are written as zero).  parts: 1 = sweep kernel, 2 = finish (3 = both).
 extern "C" int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad,
                                     int I, int I_rows, const float* h2, const float* w_nll, const int* occ_off,
-                                    const int* occ_row, float* slabs, float* gw3, float* gb3, int parts,
-                                    void* stream) {
-    SV_CHECK_ARG(w3s && h2b && h2tb && h2 && w_nll && occ_off && occ_row && slabs && gw3 && gb3,
+                                    const int* occ_row, const int* occ_items, int nocc_long, float* slabs, float* gw3,
+                                    float* gb3, int parts, void* stream) {
+    SV_CHECK_ARG(w3s && h2b && h2tb && h2 && w_nll && occ_off && occ_row && occ_items && slabs && gw3 && gb3,
                  "svae_proj_nll_bwd_dw: null pointer");
+    SV_CHECK_ARG(nocc_long >= 0 && nocc_long <= I, "svae_proj_nll_bwd_dw: bad nocc_long");
     SV_CHECK_ARG(R > 0 && I > 0 && I_rows >= I && R_pad >= R && (R_pad % BY) == 0 && parts > 0 && parts < 4,
                  "svae_proj_nll_bwd_dw: bad shape");
     hipStream_t st = (hipStream_t)stream;
@@ -754,8 +791,11 @@ extern "C" int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void
         if (int e = launch_proj<MODE_DW>(a, st)) return e;
     }
     if (parts & 2) {
-        hipLaunchKernelGGL(proj_dw_finish_kernel, dim3(I_rows), dim3(256), 0, st, slabs, h2, w_nll, occ_off, occ_row,
-                           gw3, gb3, I, I_rows);
+        if (nocc_long > 0)
+            hipLaunchKernelGGL(proj_dw_finish_long_kernel, dim3(nocc_long), dim3(64 * DWL_WAVES), 0, st, slabs, h2, w_nll, occ_off,
+                               occ_row, occ_items, gw3, gb3, I);
+        hipLaunchKernelGGL(proj_dw_finish_kernel, dim3((I_rows - nocc_long + 3) / 4), dim3(256), 0, st, slabs, h2, w_nll,
+                           occ_off, occ_row, occ_items, gw3, gb3, nocc_long, I, I_rows);
         SV_LAUNCH_CHECK();
     }
     return 0;

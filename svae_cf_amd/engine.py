@@ -320,7 +320,8 @@ class SVAEEngine:
             def proj_dw(slabs):
                 args = (self.w3s.data_ptr(), w["h2b"].data_ptr(), w["h2tb"].data_ptr(), R, Rp, I, IP,
                         w["d1"].data_ptr(), plan.w_nll.data_ptr(), plan.occ_off.data_ptr(), plan.occ_row.data_ptr(),
-                        slabs.data_ptr(), self.Gv("decoder.linear2.weight").data_ptr(),
+                        plan.occ_items.data_ptr(), plan.nocc_long, slabs.data_ptr(),
+                        self.Gv("decoder.linear2.weight").data_ptr(),
                         self.Gv("decoder.linear2.bias").data_ptr())
                 self._split_call("svae_proj_nll_bwd_dw", args, ((1, "proj_dw_fused"), (2, "proj_dw_finish")))
 
@@ -387,7 +388,7 @@ class SVAEEngine:
         ge = self.Gv("item_embed.weight")
         ge.zero_()
         _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
-                  plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, 1.0, st)
+                  plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, plan.nseg_long, 1.0, st)
         self._bucket(3)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
