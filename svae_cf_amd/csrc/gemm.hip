@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     using TA = Tile<PREC, AL>;
     using TB = Tile<PREC, BL>;
     using elem_t = typename std::conditional<PREC == 0, float, unsigned short>::type;
+    // two LDS stages: the next k-tile is written to the other stage while this one is read -> one barrier per k-tile
+    constexpr int STAGE = TA::BYTES + TB::BYTES;
     elem_t* sA = reinterpret_cast<elem_t*>(smem);
     elem_t* sB = reinterpret_cast<elem_t*>(smem + TA::BYTES);
 
@@ -182,6 +184,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = (kt + 1) < kt_end;
+        elem_t* sAn = reinterpret_cast<elem_t*>(smem + (((kt - kt_begin) & 1) ^ 1) * STAGE);
+        elem_t* sBn = reinterpret_cast<elem_t*>(smem + (((kt - kt_begin) & 1) ^ 1) * STAGE + TA::BYTES);
         if (more) {   // next tile's global loads fly under this tile's MFMAs
             TA::load(a0, a1, a2, a3, a.A, a.lda, m0, (kt + 1) * BK, a.M, a.K, tid);
             TB::load(b0, b1, b2, b3, a.B, a.ldb, n0, (kt + 1) * BK, a.N, a.K, tid);
@@ -234,12 +238,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();   // everyone is done reading this tile
         if (more) {
-            TA::store(a0, a1, a2, a3, sA, tid);
-            TB::store(b0, b1, b2, b3, sB, tid);
-            __syncthreads();
+            TA::store(a0, a1, a2, a3, sAn, tid);
+            TB::store(b0, b1, b2, b3, sBn, tid);
         }
+        __syncthreads();   // the next stage is complete; everyone is done reading this one
+        sA = sAn;
+        sB = sBn;
     }
 
     if (AL == 1 && do_cs && m0 + tid < a.M)
@@ -271,7 +276,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 template <int PREC, int AL, int BL>
 int launch(const GemmArgs& a, int nsplit, hipStream_t st) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nsplit);
-    size_t lds = Tile<PREC, AL>::BYTES + Tile<PREC, BL>::BYTES;
+    size_t lds = 2 * (Tile<PREC, AL>::BYTES + Tile<PREC, BL>::BYTES);
+    static bool attr_done = false;
+    if (!attr_done && lds > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<PREC, AL, BL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return svae_fail((int)e, "svae_gemm: LDS attribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
     hipLaunchKernelGGL((gemm_kernel<PREC, AL, BL>), grid, dim3(256), lds, st, a);
     SV_LAUNCH_CHECK();
     return 0;
