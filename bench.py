@@ -139,9 +139,33 @@ def main():
             ach, peak, unit = amount / (ms * 1e-3) / 1e9, PEAK["hbm"], "GB/s"
         rooflines[tag] = dict(bound=bound, kernel=tag, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
                               traffic=None, avg_ms=ms)
-    # the dominant kernel = the tagged kernel with the largest share of the step
-    dominant = max(rooflines, key=lambda k: rooflines[k]["avg_ms"]) if rooflines else None
-    roofline = rooflines.get(dominant)
+    # HBM bytes per launch from the PMC passes (tools/gpu_pmc.sh + tools/pmc_traffic.py: FETCH_SIZE doubled, the
+    # gfx950 correction of MI355X_MICROARCH.md; separate --pmc runs), committed under profiles/.
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_proj.json")) as f:
+            pmc = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        pass
+    for tag, r in rooflines.items():
+        if tag in pmc and "hbm_bytes" in pmc[tag]:
+            r["traffic"] = pmc[tag]["hbm_bytes"]
+    # The dominant kernel is the projection sweep, proj_kernel<MODE> (csrc/proj.hip): launched twice per step
+    # (forward + dL/dh sweep, dL/dW sweep), together the largest share of the step.  Its line covers both
+    # launches: 4 projection-sized contractions per step over the sum of the two durations.  The GRU recurrence
+    # kernels are listed in "rooflines" for completeness: they are bound by per-timestep latency, not by MFMA rate.
+    roofline = None
+    if "proj_fdh_fused" in kt and "proj_dw_fused" in kt:
+        ms = kt["proj_fdh_fused"] + kt["proj_dw_fused"]
+        ach = 4 * proj_flop / (ms * 1e-3) / 1e12
+        tr = None
+        if "traffic" in rooflines["proj_fdh_fused"] and rooflines["proj_fdh_fused"]["traffic"] and \
+                rooflines["proj_dw_fused"]["traffic"]:
+            tr = rooflines["proj_fdh_fused"]["traffic"] + rooflines["proj_dw_fused"]["traffic"]
+        roofline = dict(bound="mfma", kernel="proj_kernel (fdh + dw sweeps of one step)", achieved=ach,
+                        peak=PEAK[args.prec], unit="TFLOP/s", frac=ach / PEAK[args.prec], traffic=tr, avg_ms=ms)
+    elif rooflines:
+        roofline = rooflines[max(rooflines, key=lambda k: rooflines[k]["avg_ms"])]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
