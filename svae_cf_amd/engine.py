@@ -65,6 +65,7 @@ class SVAEEngine:
         self.w3b = self.w3tb = None
         self._last_fused = False
         self._fused_grad = False
+        self._prepped_grad = False
         self._dtmp_extra = None
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.prof = None               # dict tag -> list of (start, end) torch.cuda.Event pairs
@@ -185,6 +186,16 @@ class SVAEEngine:
         self._ensure(R)
         w, st = self.ws, _stream()
         self._plan, self._anneal = plan, float(anneal)
+        params_ready = None
+        if self.fused and self.overlap:
+            # everything that depends on the parameters only (bf16 operand copies, weight fragments, W_hh^T, the
+            # zero fill of the embedding gradient) runs on the side stream beside the embedding / GRU kernels
+            side = self._side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._param_prep(want_grad)
+                params_ready = torch.cuda.Event()
+                params_ready.record()
         _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
                   w["emb"].data_ptr(), R, self.I, st)
         self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
@@ -203,8 +214,10 @@ class SVAEEngine:
                       int(step) & 0xFFFFFFFF, st)
         if self.fused:
             # encoder -> (mu | log_sigma) -> z, KL -> decoder hidden in one kernel (bf16 MFMA mode)
-            _lib.call("svae_mlp_prep", self.P("encoder.linear1.weight").data_ptr(), self.P("linear1.weight").data_ptr(),
-                      self.P("decoder.linear1.weight").data_ptr(), self.mlp_frags.data_ptr(), st)
+            if params_ready is not None:
+                torch.cuda.current_stream().wait_event(params_ready)
+            else:
+                self._param_prep(want_grad)
             ev = self._tic("mlp_fwd")
             _lib.call("svae_mlp_fwd", w["hs"].data_ptr(), w["eps"].data_ptr(), self.mlp_frags.data_ptr(),
                       self.P("encoder.linear1.bias").data_ptr(), self.P("linear1.bias").data_ptr(),
@@ -266,15 +279,25 @@ class SVAEEngine:
             _lib.call(name, *args, bit, _stream())
             self._toc(tag, ev)
 
+    def _param_prep(self, want_grad):
+        """Per-step work that depends on the parameters only (they change at every optimizer step)."""
+        st = _stream()
+        _lib.call("svae_mlp_prep", self.P("encoder.linear1.weight").data_ptr(), self.P("linear1.weight").data_ptr(),
+                  self.P("decoder.linear1.weight").data_ptr(), self.mlp_frags.data_ptr(), st)
+        _lib.call("svae_proj_prep_items", self.P("decoder.linear2.weight").data_ptr(),
+                  self.P("decoder.linear2.bias").data_ptr(), self.I, self.IPAD, self.w3b.data_ptr(),
+                  self.w3s.data_ptr(), self.w3tb.data_ptr(), st)
+        if want_grad:
+            _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
+            self.Gv("item_embed.weight").zero_()
+        self._prepped_grad = bool(want_grad)
+
     def _proj_prepare(self, R):
-        """bf16 operand copies for the fused projection kernels (W3 changes every step)."""
+        """bf16 operand copies of the decoder hidden rows for the fused projection kernels."""
         w, st = self.ws, _stream()
         Rp = (R + 63) // 64 * 64
         _lib.call("svae_proj_prep_rows", w["d1"].data_ptr(), R, Rp, w["h2b"].data_ptr(), w["h2s"].data_ptr(),
                   w["h2tb"].data_ptr(), st)
-        _lib.call("svae_proj_prep_items", self.P("decoder.linear2.weight").data_ptr(),
-                  self.P("decoder.linear2.bias").data_ptr(), self.I, self.IPAD, self.w3b.data_ptr(),
-                  self.w3s.data_ptr(), self.w3tb.data_ptr(), st)
 
     def dense_logits(self, rows_idx=None):
         """Dense logits [n, I] for all rows of the last forward (rows_idx None) or a gathered subset
@@ -366,7 +389,9 @@ class SVAEEngine:
             chain_done = torch.cuda.Event()
             chain_done.record()
         # GRU (BPTT)
-        _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
+        prepped = self.fused and self._prepped_grad
+        if not prepped:
+            _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
         ev = self._tic("gru_bwd")
         _lib.call("svae_gru_bwd", w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
                   self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
@@ -386,7 +411,9 @@ class SVAEEngine:
         self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
         # embedding: dense gradient, zero + deterministic segmented scatter-add
         ge = self.Gv("item_embed.weight")
-        ge.zero_()
+        if not prepped:
+            ge.zero_()
+        self._prepped_grad = False
         _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
                   plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, plan.nseg_long, 1.0, st)
         self._bucket(3)
