@@ -43,6 +43,12 @@ int svae_gemm(const float* A, const float* B, float* C, const float* bias, const
               int N, int K, int lda, int ldb, int ldc, int ldaux, int a_layout, int b_layout, int act, int prec,
               int nsplit, long long slab_stride, void* stream);
 int svae_reduce_slabs(const float* slabs, float* out, long long n, int nsplit, long long slab_stride, void* stream);
+/* Weight + bias gradient of a Linear layer (autograd of y = x W^T + b, nb:1205), bf16 MFMA path:
+ * gW[n][k] = sum_r dy[r][n] x[r][k], gb[n] = sum_r dy[r][n].  The rows are split nsplit ways; split z writes
+ * gW at out + z*slab_stride and gb at colsum + z*slab_stride (colsum may be NULL); sum with svae_reduce_slabs.
+ * See csrc/wgrad.hip. */
+int svae_wgrad(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy, int ldx,
+               int nsplit, long long slab_stride, void* stream);
 
 /* ---- item embedding ----------------------------------------------------------------------------
  * svae_embed_fwd replaces self.item_embed(x) nb:756: out[r][:] = table[x[r]][:] (E = 256).

@@ -21,6 +21,7 @@ _U = _c.c_uint
 SIGNATURES = {
     "svae_gemm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _P],
     "svae_reduce_slabs": [_P, _P, _LL, _I, _LL, _P],
+    "svae_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _LL, _P],
     "svae_gru_fwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
     "svae_gru_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "svae_embed_fwd": [_P, _P, _P, _I, _I, _P],

@@ -8,7 +8,7 @@
 //   BL 0: B stored [N][K] (k contiguous)     BL 1: B stored [K][N] (n contiguous)
 // so y = x W^T is (0,0), dx = dy W is (0,1), dW = dy^T x is (1,1) with A = dy, B = x.
 // Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.
-// Split-K over blockIdx.z writes one fp32 slab per split (deterministic; reduced by reduce_slabs).
+// Split-K writes one fp32 slab per split (deterministic; reduced by reduce_slabs).
 //
 // MFMA k-order freedom: the products only have to pair A(m,k) with B(k,n) for the same k, so a
 // lane may take 4 (fp32) / 8 (bf16) CONSECUTIVE k's from one 16-byte LDS read and feed them to
@@ -29,6 +29,7 @@ struct GemmArgs {
     int act;            // 0 none, 1 tanh, 2 multiply by (1 - aux^2)  (tanh backward)
     int ktiles_per_split;
     long long slab_stride;
+    int nx, ny, nz;     // logical grid: column blocks, row blocks, k-splits
 };
 
 // Staging is split (register staging, issue-early / write-late): load() puts a thread's 4 float4 of the
@@ -154,8 +155,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kt_begin = blockIdx.z * a.ktiles_per_split;
+    // XCD-aware block order (1-D grid; workgroups are dealt round-robin over the 8 XCDs, so id % 8 names an XCD):
+    // the blocks that read the same operand panel -- the nx*ny blocks of one k-split, or the nx blocks of one
+    // row panel when there is no split -- get consecutive slots of ONE XCD, whose L2 then serves the panel's
+    // re-reads (in x-fastest order they sat on 8 different XCDs and every re-read went out to the fabric:
+    // 250 MB fetched for 80 MB of weight-gradient operands).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int bx, by, bz;
+    if (a.nz > 1) {
+        const int gsize = a.nx * a.ny, g = xcd + 8 * (slot / gsize), mem = slot % gsize;
+        if (g >= a.nz) return;
+        bz = g; bx = mem % a.nx; by = mem / a.nx;
+    } else {
+        const int g = xcd + 8 * (slot / a.nx);
+        if (g >= a.ny) return;
+        bz = 0; by = g; bx = slot % a.nx;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kt_begin = bz * a.ktiles_per_split;
     int kt_end = kt_begin + a.ktiles_per_split;
     const int kt_total = (a.K + BK - 1) / BK;
     if (kt_end > kt_total) kt_end = kt_total;
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
     const int li = lane & 31, kk = lane >> 5;
     // bias-gradient fold: the first column-tile's workgroups also sum their A tile over k
-    const bool do_cs = (AL == 1) && a.colsum != nullptr && blockIdx.x == 0 && tid < BM;
+    const bool do_cs = (AL == 1) && a.colsum != nullptr && bx == 0 && tid < BM;
     float cs = 0.f;
 
     float4 a0, a1, a2, a3, b0, b1, b2, b3;
@@ -248,10 +265,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     }
 
     if (AL == 1 && do_cs && m0 + tid < a.M)
-        a.colsum[(size_t)blockIdx.z * a.slab_stride + m0 + tid] = cs;
+        a.colsum[(size_t)bz * a.slab_stride + m0 + tid] = cs;
 
     // epilogue: C layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* C = a.C + (size_t)blockIdx.z * a.slab_stride;
+    float* C = a.C + (size_t)bz * a.slab_stride;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn + 32 * j + li;
@@ -274,8 +291,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 }
 
 template <int PREC, int AL, int BL>
-int launch(const GemmArgs& a, int nsplit, hipStream_t st) {
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nsplit);
+int launch(GemmArgs a, int nsplit, hipStream_t st) {
+    a.nx = (a.N + BN - 1) / BN;
+    a.ny = (a.M + BM - 1) / BM;
+    a.nz = nsplit;
+    const int ngroups = nsplit > 1 ? nsplit : a.ny, gsize = nsplit > 1 ? a.nx * a.ny : a.nx;
+    dim3 grid(8 * ((ngroups + 7) / 8) * gsize);
     size_t lds = 2 * (Tile<PREC, AL>::BYTES + Tile<PREC, BL>::BYTES);
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {

@@ -1,0 +1,179 @@
+// Weight-gradient GEMM of a Linear layer for gfx950 (bf16 MFMA, fp32 accumulate):
+//     gW[n][k] = sum_r dY[r][n] X[r][k],    gb[n] = sum_r dY[r][n]          (autograd of y = x W^T + b, nb:1205)
+// The contraction runs over the ROWS, the slow index of both operands, and the outputs are small (at most
+// 672 x 256) while R is ~20k: split over row ranges, one fp32 slab per range (deterministic, summed by
+// svae_reduce_slabs).  The generic LDS-tiled GEMM ran these at 0.7 TB/s: a block's k-loop is a serial chain
+// of global load -> transpose -> LDS -> barrier -> 8 MFMAs with one tile in flight and 1.5 blocks per CU.
+// Here the fp32 operand tiles go to LDS untouched by LDS-DMA (buffer_load ... lds: rows beyond R read as 0),
+// three tiles in flight per block; a wave builds its bf16 fragments from the row-major tile with conflict-free
+// column reads (lanes = consecutive columns) -- no staging registers, no transposing stores.
+#include "common.h"
+
+namespace {
+
+constexpr int WM = 128, WN = 128;   // output tile: WM dY-columns x WN X-columns
+constexpr int WK = 16;              // rows per stage = one MFMA k-step
+constexpr int NST = 4;              // LDS stages
+constexpr int TILE_BYTES = WK * WM * 4;             // 8 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;         // 16 KiB
+constexpr unsigned BUF_FLAGS = 0x00020000u;
+
+struct WgradArgs {
+    const float* dy;    // [R][ldy]
+    const float* x;     // [R][ldx]
+    float* out;         // slab z: out + z * slab_stride, [N][K] then (colsum) [N]
+    float* colsum;      // out-relative pointer of slab 0's bias gradient, or nullptr
+    int R, N, K, ldy, ldx;
+    int nx, ny, nz, tiles_per_split;
+    long long slab_stride;
+};
+
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+    const bf16v2 h = __builtin_convertvector((f32x2){a, b}, bf16v2);
+    return __builtin_bit_cast(unsigned, h);
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    // blocks of one row split sit on one XCD (id % 8), see gemm.hip
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gsize = a.nx * a.ny, bz = xcd + 8 * (slot / gsize), mem = slot % gsize;
+    if (bz >= a.nz) return;
+    const int bx = mem % a.nx, by = mem / a.nx;
+    const int m0 = by * WM, n0 = bx * WN;
+    const int ntiles = (a.R + WK - 1) / WK;
+    const int t_begin = bz * a.tiles_per_split;
+    int t_end = t_begin + a.tiles_per_split;
+    if (t_end > ntiles) t_end = ntiles;
+
+    const __amdgpu_buffer_rsrc_t dyb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((size_t)a.R * a.ldy * 4), BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((size_t)a.R * a.ldx * 4), BUF_FLAGS);
+    // one piece = one wave-instruction = 2 tile rows x 128 columns; a tile is 8 pieces per operand, wave w
+    // issues pieces w and w + 4 of both.  Columns beyond the operand's width fall into the next row (finite
+    // garbage that only reaches output rows / columns that are never stored) or beyond the buffer (zeros).
+    const unsigned colA = (unsigned)(m0 + 4 * (lane & 31)) * 4u, colB = (unsigned)(n0 + 4 * (lane & 31)) * 4u;
+    const unsigned rowl = (unsigned)(lane >> 5);
+#define SV_WG_STAGE(t_, st_)                                                                                   \
+    {                                                                                                          \
+        char* l_ = smem + (st_) * STAGE_BYTES + wave * 1024;                                                    \
+        const unsigned r0_ = (unsigned)(t_) * WK + 2 * wave + rowl;                                             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)l_, 16,          \
+                                                 r0_ * (unsigned)a.ldy * 4u + colA, 0, 0, 0);                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)(l_ + 4096), 16, \
+                                                 (r0_ + 8) * (unsigned)a.ldy * 4u + colA, 0, 0, 0);             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES), 16, \
+                                                 r0_ * (unsigned)a.ldx * 4u + colB, 0, 0, 0);                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES + 4096), 16, \
+                                                 (r0_ + 8) * (unsigned)a.ldx * 4u + colB, 0, 0, 0);             \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool do_cs = a.colsum != nullptr && bx == 0 && tid < WM;
+    float cs = 0.f;
+
+    // prologue: three tiles in flight (a missing tile is simply not issued; counted waits below assume 4 pieces
+    // per issued tile, so the tail drains with vmcnt(0))
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (t_begin + p < t_end) SV_WG_STAGE(t_begin + p, p)
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int st = (t - t_begin) & (NST - 1);
+        // own pieces of tile t landed (tiles t+1, t+2 may still be in flight: 8 younger pieces)
+        if (t + 2 < t_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // tile t complete; everyone is done reading tile t-1's stage
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < t_end) SV_WG_STAGE(t + NST - 1, (st + NST - 1) & (NST - 1))
+        const float* sA = reinterpret_cast<const float*>(smem + st * STAGE_BYTES);
+        const float* sB = sA + WK * WM;
+        if (do_cs) {
+#pragma unroll
+            for (int k = 0; k < WK; ++k) cs += sA[k * WM + tid];
+        }
+        // fragment of a 32-column group: lane (li, lh) takes rows 8 lh .. 8 lh + 7 of column base + li
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* p = sA + (8 * lh) * WM + wm + 32 * i + li;
+            uint4 u;
+            u.x = pk2(p[0], p[WM]); u.y = pk2(p[2 * WM], p[3 * WM]);
+            u.z = pk2(p[4 * WM], p[5 * WM]); u.w = pk2(p[6 * WM], p[7 * WM]);
+            fa[i] = __builtin_bit_cast(bf16x8, u);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* p = sB + (8 * lh) * WN + wn + 32 * j + li;
+            uint4 u;
+            u.x = pk2(p[0], p[WN]); u.y = pk2(p[2 * WN], p[3 * WN]);
+            u.z = pk2(p[4 * WN], p[5 * WN]); u.w = pk2(p[6 * WN], p[7 * WN]);
+            fb[j] = __builtin_bit_cast(bf16x8, u);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+#undef SV_WG_STAGE
+
+    float* C = a.out + (size_t)bz * a.slab_stride;
+    if (do_cs && m0 + tid < a.N) (a.colsum + (size_t)bz * a.slab_stride)[m0 + tid] = cs;
+    // C layout of a 32x32 tile: col = lane&31 -> X column, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> dY column
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + li;
+        if (n >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < a.N) C[(size_t)m * a.K + n] = acc[i][j][r];
+            }
+    }
+}
+
+}  // namespace
+
+// Reference interface replaced: the weight / bias gradient of one nn.Linear (or of the GRU's input / recurrent
+// weights) inside loss.backward() nb:1205.  dy [R][ldy] (N columns used), x [R][ldx] (K columns used).
+// Split z of nsplit writes gW [N][K] at out + z*slab_stride and, when colsum != NULL, gb [N] at
+// colsum + z*slab_stride (colsum usually = out + N*K); sum the slabs with svae_reduce_slabs.
+// bf16 operands (rounded from fp32 on the fly), fp32 accumulation.
+extern "C" int svae_wgrad(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
+                          int ldx, int nsplit, long long slab_stride, void* stream) {
+    SV_CHECK_ARG(dy && x && out, "svae_wgrad: null pointer");
+    SV_CHECK_ARG(R > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && (ldy % 4) == 0 && (ldx % 4) == 0,
+                 "svae_wgrad: bad shape R=%d N=%d K=%d ldy=%d ldx=%d", R, N, K, ldy, ldx);
+    SV_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0, "svae_wgrad: operands must be 16-byte aligned");
+    SV_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || slab_stride >= (long long)N * K), "svae_wgrad: bad split");
+    SV_CHECK_ARG((long long)R * ldy * 4 < (1ll << 32) && (long long)R * ldx * 4 < (1ll << 32),
+                 "svae_wgrad: operand larger than a 4 GiB buffer descriptor");
+    WgradArgs a{dy, x, out, colsum, R, N, K, ldy, ldx, (K + WN - 1) / WN, (N + WM - 1) / WM, nsplit, 0, slab_stride};
+    const int ntiles = (R + WK - 1) / WK;
+    a.tiles_per_split = (ntiles + nsplit - 1) / nsplit;
+    const int gsize = a.nx * a.ny;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+        if (e != hipSuccess) return svae_fail((int)e, "svae_wgrad: LDS attribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
+                       (hipStream_t)stream, a);
+    SV_LAUNCH_CHECK();
+    return 0;
+}

@@ -9,6 +9,7 @@ Reference path replaced: Model.forward nb:752-768, VAELoss.forward nb:795-812,
 loss.backward() nb:1205, optimizer.step() nb:1206, scoring in evaluate() nb:615-636.
 """
 import math
+import os
 
 import torch
 
@@ -48,7 +49,7 @@ class SVAEEngine:
         self.loss_out = torch.zeros(4, **f32)
         self.cap = 0
         self.ws = {}
-        self.nsplit = 32
+        self.nsplit = int(os.environ.get("SVAE_NSPLIT", "32"))   # row splits of the weight-gradient GEMMs
         self.slabs = torch.zeros(self.nsplit * (G * E + G), **f32)        # largest split-K output: dW_ih
         self.slabs_side = torch.zeros(self.nsplit * (DP * HP + DP), **f32)  # side-stream weight gradients
         # Backward runs on two streams: the data-gradient chain that leads to the GRU's BPTT (a 16-64 CU kernel,
@@ -161,11 +162,22 @@ class SVAEEngine:
         right behind the weight gradient in the flat buffer (layout.py keeps them adjacent)."""
         out = self.grads[self.layout.offset(wname):]
         slabs = self.slabs if slabs is None else slabs
-        ns = max(1, min(self.nsplit, (R + 255) // 256))
+        ns = max(1, min(self.nsplit, (R + 127) // 128))
+        stride = N * K + N
+        if self.prec == PREC_BF16:
+            ev = self._tic("wgrad")
+            if ns == 1:
+                _lib.call("svae_wgrad", dY.data_ptr(), X.data_ptr(), out.data_ptr(), out[N * K:].data_ptr(), R, N, K,
+                          ldy, ldx, 1, 0, _stream())
+            else:
+                _lib.call("svae_wgrad", dY.data_ptr(), X.data_ptr(), slabs.data_ptr(), slabs[N * K:].data_ptr(), R, N, K,
+                          ldy, ldx, ns, stride, _stream())
+                _lib.call("svae_reduce_slabs", slabs.data_ptr(), out.data_ptr(), stride, ns, stride, _stream())
+            self._toc("wgrad", ev)
+            return
         if ns == 1:
             self._gemm(dY, X, out, N, K, R, ldy, ldx, K, 1, 1, colsum=out[N * K:])
         else:
-            stride = N * K + N
             self._gemm(dY, X, slabs, N, K, R, ldy, ldx, K, 1, 1, nsplit=ns, slab_stride=stride,
                        colsum=slabs[N * K:])
             _lib.call("svae_reduce_slabs", slabs.data_ptr(), out.data_ptr(), stride, ns, stride, _stream())
