@@ -327,10 +327,11 @@ constexpr int WL_FRAGS = 21;                       // fragments of the LDS-resid
 // (lane-linear 16-byte reads, conflict-free): 6 tiles x 21 KiB = 126 KiB.
 constexpr int WLF_ELEMS = 6 * WL_FRAGS * 64 * 8;
 constexpr int FWD_WAVES = 8;
+constexpr int XS_FLOATS = 2 * 3 * 64;              // re-deal scratch of one wave: [tile][gate][user][unit]
 
 template <int NQ>  // number of hidden tiles this wave owns (2 for waves 0..5; 1 for waves 6,7)
 __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned short* h_bf, unsigned short* w_lds,
-                                                  int wave, int lane) {
+                                                  float* xs, int wave, int lane) {
     const int u0 = blockIdx.x * MU;
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_HP / 32;  // 7 k-steps
@@ -357,18 +358,18 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
 #pragma unroll
         for (int g = 0; g < 3; ++g) bias[q][g] = a.bhh[g * SV_HP + 16 * (wave + 8 * q) + ln];
 
-    f32x2 hreg[NQ][2];   // h_{t-1} of the owned elements, as (r, r+1) pairs: the gate math runs on v_pk_* ops
+    // Element roles.  The MFMA leaves the 4 real users of a tile in the four accumulator registers of lanes
+    // 0..15 (rows 0..3 of the C layout); lanes 16..63 hold padding rows.  Gate math, loads and stores on that
+    // layout run 8 elements per lane of which 2 are real.  So the accumulators are re-dealt through a small
+    // per-wave LDS scratch: lane 16 u + n takes user u of unit n -- one element per owned tile, every lane busy,
+    // a quarter of the vector and memory instructions.
+    float hreg[NQ];      // h_{t-1} of the owned elements (user lk, unit 16 (wave + 8 q) + ln)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) hreg[q][h] = (f32x2){0.f, 0.f};
+    for (int q = 0; q < NQ; ++q) hreg[q] = 0.f;
 
-    // The step body is ONE basic block: loads are clamped, stores of inactive users go to a trash row
-    // (row R, allocated by the caller), the matmul also runs at t = 0 (h = 0).
+    // The step body is ONE basic block apart from the scratch write of lanes 0..15: loads of inactive users get an
+    // out-of-range buffer offset (read 0, stores dropped), the matmul also runs at t = 0 (h = 0).
     const sv_const_int_p nact_s = sv_scalar_ptr(a.nact), roff_s = sv_scalar_ptr(a.row_off);
-    // Global traffic goes through raw buffer descriptors: a lane whose accumulator rows are padding or whose
-    // user has ended gets an out-of-range offset, so its loads return 0 and its stores are dropped without
-    // a branch (the step stays one basic block) and without touching memory.
     const unsigned R = (unsigned)roff_s[a.Tmax];
     const __amdgpu_buffer_rsrc_t gi_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, R * (SV_G * 4u), SV_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t hs_b = __builtin_amdgcn_make_buffer_rsrc(a.hs, 0, R * (SV_HP * 4u), SV_BUF_FLAGS);
@@ -391,26 +392,20 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
         const int na_next = (t + 1 < a.Tmax) ? nact_s[tn] : 0;
         const int rbase_next = roff_s[tn] + u0;
 
-        // 32-bit byte offsets of this lane's four rows (the host bounds B*Tmax so that they stay below 2^31)
-        unsigned ogi[4], ohs[4], og4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool act = 4 * lk + r < MU && u0 + 4 * lk + r < na;
-            const unsigned row = rbase + 4 * lk + r;
-            ogi[r] = act ? (row * SV_G + 16 * wave + ln) * 4u : SV_BUF_OOB;
-            ohs[r] = act ? (row * SV_HP + 16 * wave + ln) * 4u : SV_BUF_OOB;
-            og4[r] = act ? (row * SV_HP + 16 * wave + ln) * 16u : SV_BUF_OOB;
-        }
+        // 32-bit byte offsets of this lane's row (the host bounds B*Tmax so that they stay below 2^31)
+        const bool act = lk < MU && u0 + lk < na;
+        const unsigned row = rbase + lk;
+        const unsigned ogi = act ? (row * SV_G + 16 * wave + ln) * 4u : SV_BUF_OOB;
+        const unsigned ohs = act ? (row * SV_HP + 16 * wave + ln) * 4u : SV_BUF_OOB;
+        const unsigned og4 = act ? (row * SV_HP + 16 * wave + ln) * 16u : SV_BUF_OOB;
 
         // input-side gates of this step: issued before the matmul so they land behind it
-        float gi[NQ][4][3];
+        float gi[NQ][3];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    gi[q][r][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gi_b, ogi[r] + (g * SV_HP + 128 * q) * 4, 0, 0));
+            for (int g = 0; g < 3; ++g)
+                gi[q][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gi_b, ogi + (g * SV_HP + 128 * q) * 4, 0, 0));
 
         bf16x8 A[KS];
 #pragma unroll
@@ -458,57 +453,52 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
         SV_TS(2)
 #undef SV_WLOAD
 #undef SV_PIN_ORDER
-        f32x2 s_hn[NQ][2], s_hp[NQ][2], s_rg[NQ][2], s_zg[NQ][2], s_ng[NQ][2], s_gh[NQ][2];
+        // re-deal: lanes 0..15 (rows 0..3 = the real users) publish, every lane picks its (user lk, unit ln) values
+        if (lk == 0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xs[((q * 3 + g) * 4 + r) * 16 + ln] = acc[q][g][r];
+        }
+        // other LANES read what these stores wrote: the compiler only orders a thread's own aliasing accesses,
+        // so pin the order (the LDS itself executes a wave's instructions in order)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        float gh[NQ][3];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gh[q][g] = xs[(q * 3 + g) * 64 + lane];
 #ifdef SV_GRU_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         SV_TS(3)
+        float s_hn[NQ], s_hp[NQ], s_rg[NQ], s_zg[NQ], s_ng[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int j = 16 * (wave + 8 * q) + ln;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r0 = 2 * h, r1 = 2 * h + 1;
-                const f32x2 ghr = {acc[q][0][r0], acc[q][0][r1]}, ghz = {acc[q][1][r0], acc[q][1][r1]};
-                const f32x2 ghn = {acc[q][2][r0], acc[q][2][r1]};
-                const f32x2 gir = {gi[q][r0][0], gi[q][r1][0]}, giz = {gi[q][r0][1], gi[q][r1][1]};
-                const f32x2 gin = {gi[q][r0][2], gi[q][r1][2]};
-                f32x2 er = (gir + ghr) * -1.4426950408889634f, ez = (giz + ghz) * -1.4426950408889634f;
-                er = (f32x2){__builtin_amdgcn_exp2f(er.x), __builtin_amdgcn_exp2f(er.y)} + 1.0f;
-                ez = (f32x2){__builtin_amdgcn_exp2f(ez.x), __builtin_amdgcn_exp2f(ez.y)} + 1.0f;
-                const f32x2 rg = {__builtin_amdgcn_rcpf(er.x), __builtin_amdgcn_rcpf(er.y)};
-                const f32x2 zg = {__builtin_amdgcn_rcpf(ez.x), __builtin_amdgcn_rcpf(ez.y)};
-                f32x2 en = __builtin_elementwise_fma(rg, ghn, gin) * -2.8853900817779268f;
-                en = (f32x2){__builtin_amdgcn_exp2f(en.x), __builtin_amdgcn_exp2f(en.y)} + 1.0f;
-                const f32x2 tn = {__builtin_amdgcn_rcpf(en.x), __builtin_amdgcn_rcpf(en.y)};
-                const f32x2 ng = tn * 2.0f - 1.0f;
-                const f32x2 hp = hreg[q][h];
-                const f32x2 hn = __builtin_elementwise_fma(zg, hp - ng, ng);
-                hreg[q][h] = hn;
-                s_hn[q][h] = hn; s_hp[q][h] = hp; s_rg[q][h] = rg; s_zg[q][h] = zg; s_ng[q][h] = ng; s_gh[q][h] = ghn;
-                const unsigned pk = pack_bf16(hn.x, hn.y);
-                hnxt[(4 * lk + r0) * HLDB + j] = (unsigned short)(pk & 0xffffu);
-                hnxt[(4 * lk + r1) * HLDB + j] = (unsigned short)(pk >> 16);
-            }
+            const float er = __builtin_amdgcn_exp2f((gi[q][0] + gh[q][0]) * -1.4426950408889634f) + 1.0f;
+            const float ez = __builtin_amdgcn_exp2f((gi[q][1] + gh[q][1]) * -1.4426950408889634f) + 1.0f;
+            const float rg = __builtin_amdgcn_rcpf(er), zg = __builtin_amdgcn_rcpf(ez);
+            const float en = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, gh[q][2], gi[q][2]) * -2.8853900817779268f) + 1.0f;
+            const float ng = __builtin_amdgcn_rcpf(en) * 2.0f - 1.0f;
+            const float hp = hreg[q];
+            const float hn = __builtin_fmaf(zg, hp - ng, ng);
+            hreg[q] = hn;
+            s_hn[q] = hn; s_hp[q] = hp; s_rg[q] = rg; s_zg[q] = zg; s_ng[q] = ng;
+            if (lk < MU) hnxt[lk * HLDB + j] = sv_f2bf(hn);
         }
         SV_TS(4)
 #ifndef SV_EXP_NOSTORE
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r0 = 2 * h, r1 = 2 * h + 1;
-                // (float temporaries: __builtin_bit_cast on a vector component reads component 0)
-                const float hn0 = s_hn[q][h].x, hn1 = s_hn[q][h].y, hp0 = s_hp[q][h].x, hp1 = s_hp[q][h].y;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn0), hs_b, ohs[r0] + 512 * q, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hn1), hs_b, ohs[r1] + 512 * q, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hp0), hp_b, ohs[r0] + 512 * q, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hp1), hp_b, ohs[r1] + 512 * q, 0, 0);
-                const f32x4 g0 = {s_rg[q][h].x, s_zg[q][h].x, s_ng[q][h].x, s_gh[q][h].x};
-                const f32x4 g1 = {s_rg[q][h].y, s_zg[q][h].y, s_ng[q][h].y, s_gh[q][h].y};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g0), g4_b, og4[r0] + 2048 * q, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g1), g4_b, og4[r1] + 2048 * q, 0, 0);
-            }
+        for (int q = 0; q < NQ; ++q) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s_hn[q]), hs_b, ohs + 512 * q, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s_hp[q]), hp_b, ohs + 512 * q, 0, 0);
+            const f32x4 g0 = {s_rg[q], s_zg[q], s_ng[q], gh[q][2]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g0), g4_b, og4 + 2048 * q, 0, 0);
+        }
 #endif
         SV_TS(5)
         na = na_next;
@@ -532,12 +522,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void gru_fwd_bf16_kernel(GruArgs
     unsigned short* h_bf = smem_f + WLF_ELEMS;     // [2][MB][HLDB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* xs = reinterpret_cast<float*>(h_bf + 2 * MB * HLDB) + wave * XS_FLOATS;   // per-wave re-deal scratch
     for (int i = tid; i < 2 * MB * HLDB; i += 64 * FWD_WAVES) h_bf[i] = 0;
     __syncthreads();
     if (wave < 6)
-        gru_fwd_bf16_body<2>(a, h_bf, w_lds, wave, lane);
+        gru_fwd_bf16_body<2>(a, h_bf, w_lds, xs, wave, lane);
     else
-        gru_fwd_bf16_body<1>(a, h_bf, w_lds, wave, lane);
+        gru_fwd_bf16_body<1>(a, h_bf, w_lds, xs, wave, lane);
 }
 
 // Backward: same organisation as the forward (8 waves, wave w owns hidden tiles w and w+8, the second one
@@ -704,7 +695,7 @@ extern "C" int svae_gru_fwd(const float* gi, const float* whh, const float* bhh,
         grid = dim3((B + MU - 1) / MU);
         SV_CHECK_ARG((long long)B * Tmax < (1ll << 19), "svae_gru_fwd: B*Tmax = %lld rows exceed the 32-bit addressing "
                      "of the bf16 kernel (2^19 rows); split the batch", (long long)B * Tmax);
-        const int lds = (WLF_ELEMS + 2 * MB * HLDB) * sizeof(unsigned short);   // 144 KiB of the CU's 160
+        const int lds = (WLF_ELEMS + 2 * MB * HLDB) * sizeof(unsigned short) + FWD_WAVES * XS_FLOATS * 4;   // 156 KiB of the CU's 160
         hipError_t e = hipFuncSetAttribute((const void*)gru_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_fwd: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(gru_fwd_bf16_kernel, dim3((B + MU - 1) / MU), dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);

@@ -304,6 +304,8 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                     } else {
                         // Z rows are x = (r&3) + 8 (r>>2) + 4 lh: fetch the factors of those rows through LDS
                         if (lh == 0) fs[li] = f;
+                        asm volatile("" ::: "memory");      // read by other lanes: keep the compiler from reordering
+                        __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const float4 fv = *reinterpret_cast<const float4*>(fs + 8 * g + 4 * lh);
