@@ -37,6 +37,7 @@ constexpr int MU = 4;              // bf16 kernels: users a workgroup really own
                                    // padding).  The step is bound by the CU's 64 B/clk L1<->L2 path (gi, saved
                                    // gates, dgi/dgh: >100 KB per step at 16 users), so halving the users per CU
                                    // and doubling the CUs in use shortens the recurrence's critical path.
+static_assert(MU <= 4, "element roles: lane 16 u + n owns user u, so a workgroup has at most 4 users");
 constexpr int NJT = SV_HP / 16;    // 14 hidden-unit tiles of 16
 constexpr int HLD = SV_HP + 4;     // fp32 LDS row stride (floats) of the h image
 constexpr int GLD = SV_G + 4;      // fp32 LDS row stride (floats) of the dgh image
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void gru_fwd_bf16_kernel(GruArgs
 // MU real rows: the MFMA rows of padding users alias them (row = ln % MU), their results are discarded.
 template <int NQ>
 __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned short* g_bf, unsigned short* w_lds,
-                                                  int wave, int lane) {
+                                                  float* xs, int wave, int lane) {
     const int u0 = blockIdx.x * MU;
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_G / 32;  // 21 k-steps
@@ -565,68 +566,59 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
     const __amdgpu_buffer_rsrc_t gi_b = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, R * (SV_G * 4u), SV_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t gh_b = __builtin_amdgcn_make_buffer_rsrc(a.dgh, 0, R * (SV_G * 4u), SV_BUF_FLAGS);
 
-    float dh[NQ][4];
+    // Element roles as in the forward kernel: lane 16 u + n owns user u of unit n of each tile this wave owns.
+    float dh[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dh[q][r] = 0.f;
+    for (int q = 0; q < NQ; ++q) dh[q] = 0.f;
 
     // Saved forward values of a step are fetched one step ahead (issued right after the barrier, consumed
     // after the matmul of the step before), so their latency sits under the MFMAs.  Masked lanes read zeros
     // (d = 0 follows) and their stores are dropped.
-    u32x4 sg[NQ][4];
-    unsigned shp[NQ][4], sdh[NQ][4];
-    unsigned ohs[4], og4[4], ogo[4];
-    bool actv[4];
+    u32x4 sg[NQ];
+    unsigned shp[NQ], sdh[NQ];
+    unsigned ohs, og4, ogo;
+    bool actv;
 #define SV_GRU_BWD_FETCH(t_)                                                                                \
     {                                                                                                       \
         const int na_ = nact_s[t_];                                                                         \
-        const int rbase_ = roff_s[t_] + u0;                                                                 \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                     \
-            actv[r] = 4 * lk + r < MU && u0 + 4 * lk + r < na_;                                             \
-            const unsigned row = rbase_ + 4 * lk + r;                                                       \
-            ohs[r] = actv[r] ? (row * SV_HP + 16 * wave + ln) * 4u : SV_BUF_OOB;                            \
-            og4[r] = actv[r] ? (row * SV_HP + 16 * wave + ln) * 16u : SV_BUF_OOB;                           \
-            ogo[r] = actv[r] ? (row * SV_G + 16 * wave + ln) * 4u : SV_BUF_OOB;                             \
+        const unsigned row = roff_s[t_] + u0 + lk;                                                          \
+        actv = lk < MU && u0 + lk < na_;                                                                    \
+        ohs = actv ? (row * SV_HP + 16 * wave + ln) * 4u : SV_BUF_OOB;                                      \
+        og4 = actv ? (row * SV_HP + 16 * wave + ln) * 16u : SV_BUF_OOB;                                     \
+        ogo = actv ? (row * SV_G + 16 * wave + ln) * 4u : SV_BUF_OOB;                                       \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                    \
+            sg[q] = __builtin_amdgcn_raw_buffer_load_b128(g4_b, og4 + 2048 * q, 0, 0);                      \
+            shp[q] = __builtin_amdgcn_raw_buffer_load_b32(hp_b, ohs + 512 * q, 0, 0);                       \
+            sdh[q] = __builtin_amdgcn_raw_buffer_load_b32(dh_b, ohs + 512 * q, 0, 0);                       \
         }                                                                                                   \
-        _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                      \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
-                sg[q][r] = __builtin_amdgcn_raw_buffer_load_b128(g4_b, og4[r] + 2048 * q, 0, 0);            \
-                shp[q][r] = __builtin_amdgcn_raw_buffer_load_b32(hp_b, ohs[r] + 512 * q, 0, 0);             \
-                sdh[q][r] = __builtin_amdgcn_raw_buffer_load_b32(dh_b, ohs[r] + 512 * q, 0, 0);             \
-            }                                                                                               \
     }
     if (Tw > 0) SV_GRU_BWD_FETCH(Tw - 1)
     for (int t = Tw - 1; t >= 0; --t) {
         unsigned short* gcur = g_bf + (t & 1) * (MU * GLDB);
-        float carry[NQ][4];
+        float carry[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int j = 16 * (wave + 8 * q) + ln;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rg = __uint_as_float(sg[q][r].x), zg = __uint_as_float(sg[q][r].y);
-                const float ng = __uint_as_float(sg[q][r].z), ghn = __uint_as_float(sg[q][r].w);
-                const float d = actv[r] ? dh[q][r] + __uint_as_float(sdh[q][r]) : 0.f;
-                const float dn = d * (1.0f - zg);
-                const float dzg = d * (__uint_as_float(shp[q][r]) - ng);
-                const float dnp = dn * (1.0f - ng * ng);
-                const float dzp = dzg * zg * (1.0f - zg);
-                const float drp = dnp * ghn * rg * (1.0f - rg);
-                const float dnr = dnp * rg;
-                carry[q][r] = d * zg;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gi_b, ogo[r] + 512 * q, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gi_b, ogo[r] + 512 * q + SV_HP * 4, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnp), gi_b, ogo[r] + 512 * q + 2 * SV_HP * 4, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gh_b, ogo[r] + 512 * q, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gh_b, ogo[r] + 512 * q + SV_HP * 4, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnr), gh_b, ogo[r] + 512 * q + 2 * SV_HP * 4, 0, 0);
-                if (4 * lk + r < MU) {   // compile-time for r when MU % 4 == 0: only lanes lk < MU/4 own image rows
-                    const int m = 4 * lk + r;
-                    gcur[m * GLDB + j] = sv_f2bf(drp);
-                    gcur[m * GLDB + SV_HP + j] = sv_f2bf(dzp);
-                    gcur[m * GLDB + 2 * SV_HP + j] = sv_f2bf(dnr);
-                }
+            const float rg = __uint_as_float(sg[q].x), zg = __uint_as_float(sg[q].y);
+            const float ng = __uint_as_float(sg[q].z), ghn = __uint_as_float(sg[q].w);
+            const float d = actv ? dh[q] + __uint_as_float(sdh[q]) : 0.f;
+            const float dn = d * (1.0f - zg);
+            const float dzg = d * (__uint_as_float(shp[q]) - ng);
+            const float dnp = dn * (1.0f - ng * ng);
+            const float dzp = dzg * zg * (1.0f - zg);
+            const float drp = dnp * ghn * rg * (1.0f - rg);
+            const float dnr = dnp * rg;
+            carry[q] = d * zg;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gi_b, ogo + 512 * q, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gi_b, ogo + 512 * q + SV_HP * 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnp), gi_b, ogo + 512 * q + 2 * SV_HP * 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gh_b, ogo + 512 * q, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gh_b, ogo + 512 * q + SV_HP * 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnr), gh_b, ogo + 512 * q + 2 * SV_HP * 4, 0, 0);
+            if (lk < MU) {   // MU = 4: every lane owns an image row
+                gcur[lk * GLDB + j] = sv_f2bf(drp);
+                gcur[lk * GLDB + SV_HP + j] = sv_f2bf(dzp);
+                gcur[lk * GLDB + 2 * SV_HP + j] = sv_f2bf(dnr);
             }
         }
         __syncthreads();  // dgh_t published (ping-pong: step t-1 writes the other buffer)
@@ -650,10 +642,19 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
                     }
                 }
             }
+            // re-deal dh_{t-1} = carry + dgh W_hh: rows 0..3 of the C tile (lanes 0..15) -> lane 16 u + n
+            if (lk == 0) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dh[q][r] = carry[q][r] + acc[q][r];
+                    for (int r = 0; r < 4; ++r) xs[(q * 4 + r) * 16 + ln] = acc[q][r];
+            }
+            asm volatile("" ::: "memory");      // read by other lanes: keep the compiler from reordering
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) dh[q] = carry[q] + xs[q * 64 + lane];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 #undef SV_GRU_BWD_FETCH
@@ -665,10 +666,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void gru_bwd_bf16_kernel(GruArgs
     unsigned short* g_bf = smem_b + WLF_ELEMS;     // [2][MU][GLDB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* xs = reinterpret_cast<float*>(g_bf + 2 * MU * GLDB) + wave * 128;     // per-wave re-deal scratch
     if (wave < 6)
-        gru_bwd_bf16_body<2>(a, g_bf, w_lds, wave, lane);
+        gru_bwd_bf16_body<2>(a, g_bf, w_lds, xs, wave, lane);
     else
-        gru_bwd_bf16_body<1>(a, g_bf, w_lds, wave, lane);
+        gru_bwd_bf16_body<1>(a, g_bf, w_lds, xs, wave, lane);
 }
 
 }  // namespace
@@ -720,7 +722,7 @@ extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* g
         grid = dim3((B + MU - 1) / MU);
         SV_CHECK_ARG((long long)B * Tmax < (1ll << 19), "svae_gru_bwd: B*Tmax = %lld rows exceed the 32-bit addressing "
                      "of the bf16 kernel (2^19 rows); split the batch", (long long)B * Tmax);
-        const int lds = (WLF_ELEMS + 2 * MU * GLDB) * sizeof(unsigned short);
+        const int lds = (WLF_ELEMS + 2 * MU * GLDB) * sizeof(unsigned short) + FWD_WAVES * 128 * 4;
         hipError_t e = hipFuncSetAttribute((const void*)gru_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_bwd: LDS attribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(gru_bwd_bf16_kernel, grid, dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);
