@@ -187,7 +187,7 @@ class SVAEEngine:
         _lib.call("svae_colsum", A.data_ptr(), out.data_ptr(), self.colparts.data_ptr(), R, N, ld, nparts, _stream())
 
     # ------------------------------------------------------------------ forward
-    def forward(self, plan, anneal=0.0, eps=None, seed=0, step=0, want_grad=True, want_loss=True):
+    def forward(self, plan, anneal=0.0, eps=None, seed=0, step=0, want_grad=True, want_loss=True, defer_loss=False):
         """Encoder GRU -> latent -> decoder -> logits (+ loss and dlogits).
 
         eps: optional [R, 64] fp32 device tensor in plan row order (parity mode: the reference's
@@ -262,8 +262,17 @@ class SVAEEngine:
                           plan.tgt.data_ptr(), R, self.I, plan.K, w["part"].data_ptr(), w["nll_row"].data_ptr(),
                           w["lse"].data_ptr(), st)
             self._fused_grad = bool(want_grad)
-            _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
-                      plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
+            if defer_loss and want_grad and self.overlap:
+                # nothing in backward reads the scalar loss: reduce it on the side stream (joined at the end of backward)
+                side = self._side_stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(),
+                              plan.w_nll.data_ptr(), plan.w_kl.data_ptr(), float(anneal), R,
+                              self.loss_out.data_ptr(), _stream())
+            else:
+                _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
+                          plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
             return self.loss_out
         self._last_fused = False
         if not want_loss:
@@ -486,7 +495,7 @@ class SVAEEngine:
     def train_step(self, plan, anneal, eps=None, seed=0, step=None):
         """forward + backward + Adam for one batch.  Returns the device tensor holding
         [loss, likelihood, KL]; reading it synchronises, so do that only when logging."""
-        self.forward(plan, anneal, eps=eps, seed=seed, step=self.step_count if step is None else step)
+        self.forward(plan, anneal, eps=eps, seed=seed, step=self.step_count if step is None else step, defer_loss=True)
         self.backward()
         if self.grad_sync is not None:
             self.grad_sync.wait()
