@@ -42,23 +42,31 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # SVAE_DIST_BACKEND=gloo is the rehearsal mode for a one-GPU box (tools/dp_rehearsal.sh): the ranks share
+    # the card and the all-reduce goes through gloo; the driver's runs use the default, nccl (= RCCL over xGMI)
+    backend = os.environ.get("SVAE_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     import svae_cf_amd as S
     from svae_cf_amd import synth
-    from svae_cf_amd.dist import GradSync
+    from svae_cf_amd.dist import GradSync, rank_batches
 
     I, B = args.items, args.batch
     _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
     n_users = args.nplans * B * world
     users = synth.make_users(n_users, I, mu, sigma, lmax, seed=98765)
     rng = np.random.default_rng(98765)
-    batches = synth.bucketed_batches([len(u) for u in users], B, rng)
-    mine = [batches[i] for i in range(rank, len(batches) // world * world, world)]
+    # every rank builds the same seeded order; a global batch (B*world users of similar length) is dealt
+    # round-robin to the ranks, so rows and Tmax per step are balanced across ranks (dist.rank_batches)
+    mine = rank_batches([len(u) for u in users], B, rng, rank, world)
     plans = [S.build_plan([users[i] for i in idx], 4, user_keys=idx, device=dev, total_items=I) for idx in mine]
     rows = float(np.mean([p.R for p in plans]))
 

@@ -1,7 +1,8 @@
 """User-sharded data parallelism (NEW in this build: the reference is single-process).
 
 One process per GPU.  Users (independent sequences) are sharded: every rank builds the same seeded
-global batch order and takes every world-th batch.  Parameters and Adam state are replicated; each
+global batch order; a global batch (B*world users of similar length) is dealt round-robin to the ranks
+(synth.bucketed_batches(world=...)), so all ranks do the same amount of work at every step.  Parameters and Adam state are replicated; each
 step does ONE exchange: a sum all-reduce of the flat gradient buffer, issued per bucket in
 backward-readiness order (decoder.linear2 first, item_embed last) so RCCL works over xGMI while the
 rest of backward still runs; Adam then applies gscale = 1/world (mean over the union of users).
@@ -39,9 +40,20 @@ class GradSync:
 
 def shard_batches(batches, rank, world):
     """Rank r takes batches r, r+world, ...; the tail that does not fill all ranks is dropped so
-    every rank runs the same number of steps (collectives stay matched)."""
+    every rank runs the same number of steps (collectives stay matched).  Training uses the balanced form
+    ``rank_batches`` instead: with shuffled length-bucketed batches this one hands the ranks of a step
+    batches of very different lengths, and every step then lasts as long as its longest batch."""
     n = len(batches) // world * world
     return [batches[i] for i in range(rank, n, world)]
+
+
+def rank_batches(lengths, batch_size, rng, rank, world, window=16):
+    """This rank's batch of every step, balanced over ranks (see synth.bucketed_batches)."""
+    from .synth import bucketed_batches
+    steps = bucketed_batches(lengths, batch_size, rng, window=window, world=world)
+    if world == 1:
+        return steps
+    return [s[rank] for s in steps]
 
 
 def allreduce_metrics(values, device, group=None):

@@ -352,12 +352,11 @@ def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, 
                   rank=0, world=1):
     """One epoch with B users per step (length-bucketed, user-sharded over ranks).  The anneal schedule
     counts optimizer steps exactly as the notebook counts batches."""
-    from .dist import shard_batches
-    from .synth import bucketed_batches
+    from .dist import rank_batches
     eng = model.engine
     rng = np.random.default_rng(seed + 1000 * epoch)
     lens = [len(u) for u in reader.data]
-    batches = shard_batches(bucketed_batches(lens, batch_size, rng), rank, world)
+    batches = rank_batches(lens, batch_size, rng, rank, world)
     eng.grad_sync = grad_sync
     k = reader._k()
     for b, idx in enumerate(batches, start=1):

@@ -39,17 +39,36 @@ def make_users(n_users, total_items, mu, sigma, lmax, seed=98765, n_clusters=64)
     return users
 
 
-def bucketed_batches(lengths, batch_size, rng, window=16):
-    """Length-bucketed batches: shuffle users, sort inside windows of window*batch_size users,
-    cut into batches, shuffle the batches.  Returns a list of index arrays."""
+def bucketed_batches(lengths, batch_size, rng, window=16, world=1):
+    """Length-bucketed batches: shuffle users, sort inside windows of window*batch_size*world users,
+    cut into global batches of batch_size*world users, shuffle the global batches.
+
+    world == 1: returns a list of index arrays (one per step).
+    world > 1 : returns a list of steps, each a list of ``world`` index arrays (rank r's batch of that
+    step).  A global batch holds users of similar length in descending order and is dealt round-robin
+    (rank r takes positions r, r+world, ...), so at every step all ranks have the same Tmax and the same
+    number of rows to within (longest - shortest user of the global batch): the gradient all-reduce of a
+    step never waits for a rank that drew a longer batch.  A tail that does not fill every rank with the
+    same number of users is dropped (collectives stay matched)."""
     n = len(lengths)
+    lengths = np.asarray(lengths)
     perm = rng.permutation(n)
     out = []
-    w = window * batch_size
+    gb = batch_size * world
+    w = window * gb
     for s in range(0, n, w):
         idx = perm[s:s + w]
-        idx = idx[np.argsort(-np.asarray(lengths)[idx], kind="stable")]
-        for b in range(0, len(idx), batch_size):
-            out.append(idx[b:b + batch_size])
+        idx = idx[np.argsort(-lengths[idx], kind="stable")]
+        for b in range(0, len(idx), gb):
+            out.append(idx[b:b + gb])
     order = rng.permutation(len(out))
-    return [out[i] for i in order]
+    out = [out[i] for i in order]
+    if world == 1:
+        return out
+    steps = []
+    for g in out:
+        m = len(g) // world * world
+        if m == 0:
+            continue
+        steps.append([g[r:m:world] for r in range(world)])
+    return steps

@@ -172,6 +172,28 @@ def test_shard_batches_partitions_users():
     assert len(set(allu.tolist())) == len(allu)
 
 
+def test_rank_batches_balanced_and_disjoint():
+    """DP sharding: every step gives all ranks the same user count, near-equal rows and Tmax; users are
+    never shared between ranks; world=1 reproduces the plain bucketed order."""
+    from svae_cf_amd.dist import rank_batches
+    from svae_cf_amd.synth import bucketed_batches
+    lens = np.clip(np.rint(np.random.default_rng(0).lognormal(4.2, 0.9, 16 * 64 * 4)), 5, 200).astype(int)
+    world, B = 4, 64
+    parts = [rank_batches(lens, B, np.random.default_rng(7), r, world) for r in range(world)]
+    assert len({len(p) for p in parts}) == 1 and len(parts[0]) == 16
+    allu = np.concatenate([np.concatenate(p) for p in parts])
+    assert len(set(allu.tolist())) == len(allu) == len(lens)
+    for step in range(len(parts[0])):
+        rows = [int((lens[parts[r][step]] - 1).sum()) for r in range(world)]
+        tmax = [int(lens[parts[r][step]].max()) for r in range(world)]
+        assert all(len(parts[r][step]) == B for r in range(world))
+        assert max(rows) - min(rows) <= max(tmax) and max(rows) <= 1.02 * min(rows) + 8
+        assert max(tmax) - min(tmax) <= max(2, 0.1 * max(tmax))
+    one = rank_batches(lens, B, np.random.default_rng(7), 0, 1)
+    ref = bucketed_batches(lens, B, np.random.default_rng(7))
+    assert all((a == b).all() for a, b in zip(one, ref))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
