@@ -44,9 +44,12 @@ def main():
     import torch.distributed as dist
     # SVAE_DIST_BACKEND=gloo is the rehearsal mode for a one-GPU box (tools/dp_rehearsal.sh): the ranks share
     # the card and the all-reduce goes through gloo; the driver's runs use the default, nccl (= RCCL over xGMI)
+    # SVAE_DP_REHEARSAL=1: create the process group and keep the gradient all-reduces even at world size 1
+    # (the RCCL call path, stream ordering included, on a one-GPU box)
     backend = os.environ.get("SVAE_DIST_BACKEND", "nccl")
+    rehearse = os.environ.get("SVAE_DP_REHEARSAL", "0") == "1"
     dev_index = local_rank % max(1, torch.cuda.device_count()) if world > 1 else 0
-    if world > 1:
+    if world > 1 or rehearse:
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -84,12 +87,12 @@ def main():
         else:
             sd[name] = (torch.rand(shp) * 2 - 1) * 0.05
     eng.load_state_dict(sd)
-    if world > 1:
-        eng.grad_sync = GradSync(eng.grads, eng.layout.buckets())
+    if world > 1 or rehearse:
+        eng.grad_sync = GradSync(eng.grads, eng.layout.buckets(), force=rehearse)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or rehearse:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -122,7 +125,7 @@ def main():
     loss = float(eng.loss_out[0])
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     u = torch.tensor([float(users_done)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
     dt, total_users = float(t[0]), float(u[0])
@@ -213,12 +216,12 @@ def main():
             "config": {"workload": "ML-20M-shaped synthetic (configs[2]): 20000 items, seq<=200, "
                                    "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam" % B,
                        "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "parallelism": "dp%d" % world,
-                       "final_loss": loss},
+                       "final_loss": loss, "side_stream": eng.side_stream_info},
             "kernel_ms": kt, "kernel_ms_untimed_pass": kt_extra, "roofline": roofline, "rooflines": rooflines,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or rehearse:
         dist.destroy_process_group()
 
 

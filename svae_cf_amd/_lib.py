@@ -47,6 +47,7 @@ SIGNATURES = {
     "svae_mlp_prep": [_P, _P, _P, _P, _P],
     "svae_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "svae_mlp_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
+    "svae_spin": [_I, _P],
     "svae_proj_nsplit": [],
     "svae_proj_tile": [],
     "svae_check_device": [],

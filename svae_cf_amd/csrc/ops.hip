@@ -528,3 +528,21 @@ extern "C" int svae_philox_normal(float* out, const long long* row_key, int R, u
     SV_LAUNCH_CHECK();
     return 0;
 }
+
+// Stream calibration helper (no counterpart in the reference): one workgroup that stays busy for `usec`
+// microseconds of the 100 MHz wall clock.  The host launches it on two streams to find out whether they run
+// concurrently: HIP maps streams onto a few hardware queues, and two streams that share a queue execute in
+// order, whatever the stream graph says (engine.py, _pick_side_stream).  Bounded loop: the kernel always ends.
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 22); ++i) {
+        if (wall_clock64() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+extern "C" int svae_spin(int usec, void* stream) {
+    SV_CHECK_ARG(usec > 0 && usec <= 100000, "svae_spin: usec out of range");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull);
+    SV_LAUNCH_CHECK();
+    return 0;
+}

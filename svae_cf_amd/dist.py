@@ -12,21 +12,37 @@ import torch.distributed as dist
 
 
 class GradSync:
-    """Bucketed asynchronous all-reduce over a flat gradient buffer."""
+    """Bucketed all-reduce over a flat gradient buffer.
 
-    def __init__(self, flat_grads, buckets, group=None):
+    Backend nccl (= RCCL, the production path): asynchronous; the collective is ordered behind the stream that
+    is current when ``bucket_ready`` is called and runs on RCCL's own stream beside the rest of backward;
+    ``wait`` orders the caller's stream behind all of them (no host block).
+    Any other backend (gloo: the CPU tests and the one-GPU rehearsal, where ranks share a card): the bucket is
+    staged through host memory synchronously.  gloo's own device-tensor all-reduce is not used: on this ROCm
+    build it never completed (both ranks blocked in Work.wait(); seen with tests/test_gpu_dp.py).
+    ``force`` keeps the collectives at world size 1 (rehearsal of the RCCL call path on one GPU)."""
+
+    def __init__(self, flat_grads, buckets, group=None, force=False):
         self.flat = flat_grads
         self.buckets = list(buckets)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or force)
+        self.device_collectives = self.active and dist.get_backend(group) == "nccl"
         self.pending = []
 
     def bucket_ready(self, i):
         """Call when every gradient of bucket i has been enqueued on the current stream."""
-        if self.world == 1:
+        if not self.active:
             return
         s, e = self.buckets[i]
-        self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.device_collectives or not self.flat.is_cuda:
+            self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True))
+            return
+        host = self.flat[s:e].to("cpu")            # ordered behind the current stream, blocks until copied
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat[s:e].copy_(host)                 # on the current stream as well
 
     def wait(self):
         for w in self.pending:

@@ -1,0 +1,106 @@
+"""Data-parallel step on the GPU: 2 ranks that share the card (gloo all-reduce of the flat gradient buffer
+through GradSync, exactly the path bench.py and train_batched take for N>1) must reproduce the
+single-process step over the UNION of the two ranks' users.
+
+Contract checked: step over S = mean over u in S of the reference's single-user loss, so
+sum-all-reduce x 1/world of the per-rank gradients = the gradient of the union batch; Philox noise is keyed
+by (user id, t), so a user's noise does not depend on which rank holds it.
+Tolerance: parameters after 3 Adam steps, per-tensor relative L2 <= 1e-4 (the north-star gate; the two runs
+differ only in fp32 summation order, and in bf16 mode in nothing else either).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+I, B, WORLD, STEPS = 300, 24, 2, 3
+
+
+def _users():
+    from svae_cf_amd import synth
+    return synth.make_users(STEPS * B * WORLD, I, 2.8, 0.6, 60, seed=5)
+
+
+def _init_sd(layout):
+    g = torch.Generator().manual_seed(3)
+    return {n: torch.randn(s, generator=g) * 0.1 for n, s in layout.ref_shapes.items()}
+
+
+def _run(rank, world, prec, port, q):
+    sys.path.insert(0, ROOT)
+    if q is not None:
+        # a rank that stops making progress dumps its stacks and exits instead of hanging the test run
+        import faulthandler
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        fh = open(os.path.join(ROOT, "gpurun_out", "dp_test_rank%d_prec%d.trace" % (rank, prec)), "w")
+        faulthandler.dump_traceback_later(70, exit=True, file=fh)
+    import torch.distributed as dist
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    from svae_cf_amd.dist import GradSync, rank_batches
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    users = _users()
+    lens = [len(u) for u in users]
+    eng = S.SVAEEngine(I, device="cuda", prec=prec)
+    eng.load_state_dict(_init_sd(eng.layout))
+    steps = synth.bucketed_batches(lens, B, np.random.default_rng(11), world=WORLD)
+    mine = rank_batches(lens, B, np.random.default_rng(11), rank, WORLD) if world > 1 else None
+    if world > 1:
+        eng.grad_sync = GradSync(eng.grads, eng.layout.buckets())
+    losses = []
+    for s in range(STEPS):
+        idx = mine[s] if world > 1 else np.concatenate(steps[s])
+        plan = S.build_plan([users[i] for i in idx], 4, user_keys=idx, device="cuda", total_items=I)
+        out = eng.train_step(plan, 0.05, seed=77, step=s)
+        losses.append(float(out[0]))
+    torch.cuda.synchronize()
+    sd = {k: v.cpu().numpy() for k, v in eng.state_dict().items()}
+    if world > 1:
+        t = torch.tensor(losses, dtype=torch.float64)
+        dist.all_reduce(t)
+        losses = (t / world).tolist()
+        dist.destroy_process_group()
+    if q is None:
+        return sd, losses
+    if rank == 0:
+        q.put((sd, losses))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_two_ranks_equal_union_batch(prec):
+    import torch.multiprocessing as mp
+    ref_sd, ref_losses = _run(0, 1, prec, 0, None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_run, args=(r, WORLD, prec, port, q), daemon=True) for r in range(WORLD)]
+    for p in ps:
+        p.start()
+    try:
+        sd, losses = q.get(timeout=100)
+        for p in ps:
+            p.join(30)
+            assert p.exitcode == 0
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.kill()
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-5 if prec == 0 else 1e-3)
+    for k, v in ref_sd.items():
+        d = np.linalg.norm(sd[k].astype(np.float64) - v) / np.linalg.norm(v)
+        assert d <= 1e-4, (k, d)

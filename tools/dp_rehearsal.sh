@@ -1,12 +1,19 @@
 #!/bin/bash
-# Rehearsal of the N>1 bench path on a ONE-GPU box: 2 ranks share the card, gradients all-reduced through gloo.
-# Checks the launch contract (torch.distributed.run env), balanced sharding, GradSync and the rank-0 JSON line;
-# the throughput it prints means nothing (two processes on one GPU).
+# Rehearsal of the N>1 bench path on a ONE-GPU box, two legs:
+#  1. RCCL leg: 1 rank under torch.distributed.run with SVAE_DP_REHEARSAL=1 -- process group on nccl (= RCCL),
+#     the bucketed asynchronous all-reduces of GradSync issued from the backward streams, barrier, MAX/SUM
+#     reductions of the timing: the exact call path of the driver's N>1 runs, at world size 1.
+#  2. gloo leg: 2 ranks share the card, gradients staged through host memory: launch contract, balanced
+#     sharding, matched collectives, rank-0 JSON line.  Its throughput means nothing.
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT" || exit 1
 mkdir -p gpurun_out
+SVAE_DP_REHEARSAL=1 timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
+  --master-addr 127.0.0.1 --master-port 29516 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline \
+  > gpurun_out/dp_rehearsal_rccl.json 2> gpurun_out/dp_rehearsal_rccl.err || { tail -30 gpurun_out/dp_rehearsal_rccl.err; exit 1; }
+cat gpurun_out/dp_rehearsal_rccl.json
 SVAE_DIST_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-  --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 3 --nplans 4 \
-  > gpurun_out/dp_rehearsal.json 2> gpurun_out/dp_rehearsal.err || { tail -30 gpurun_out/dp_rehearsal.err; exit 1; }
+  --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 3 --nplans 4 --no-cpu-baseline \
+  > gpurun_out/dp_rehearsal.json 2> gpurun_out/dp_rehearsal.err || { tail -30 gpurun_out/dp_rehearsal.err; exit 2; }
 cat gpurun_out/dp_rehearsal.json

@@ -11,6 +11,11 @@ rng = np.random.default_rng(98765)
 batches = synth.bucketed_batches([len(u) for u in users], B, rng)
 plans = [S.build_plan([users[i] for i in idx], 4, user_keys=idx, device="cuda", total_items=I) for idx in batches]
 eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+if "--rccl" in sys.argv:      # world-size-1 process group on RCCL, all-reduces kept (needs MASTER_ADDR/PORT, RANK, WORLD_SIZE)
+    import torch.distributed as dist
+    from svae_cf_amd.dist import GradSync
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    eng.grad_sync = GradSync(eng.grads, eng.layout.buckets(), force=True)
 for i in range(8):
     eng.train_step(plans[i % 16], 0.01, seed=1)
 torch.cuda.synchronize()
