@@ -110,6 +110,8 @@ def main():
     if args.prec != "bf16":
         tags_timed = ["proj_fwd", "proj_dw", "proj_dx", "softmax_nll"]
     eng.prof = None if args.no_kernel_times else {t: [] for t in tags_timed}
+    if eng.prof is not None:
+        eng.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * len(tags_timed) * args.steps + 8)]
     barrier()
     t0 = time.perf_counter()
     users_done = 0

@@ -112,32 +112,42 @@ int svae_loss_reduce(const float* nll_row, const float* kl_row, const float* w_n
  *   svae_proj_prep_rows   bf16 copies of the decoder hidden rows h2 [R][160] (tanh of Decoder.linear1 nb:709):
  *                         h2b plain, h2s scaled by log2(e) (both [R_pad][160]), h2tb transposed [160][R_pad]
  *   svae_proj_prep_items  the same for Decoder.linear2's weight w3 [I][160] and bias b3: w3b, w3s, w3tb
- *   svae_proj_nll_fwd     loss only (scoring): nll_row[R], lse[R];  part = 16 R floats of scratch
+ *   svae_proj_nll_fwd     loss only (scoring): nll_row[R], lse[R];  part = 32 R floats of scratch
  *   svae_proj_nll_fwd_dh  forward AND the hidden-side gradient in one sweep over the items: nll_row, lse,
  *                         dd1 [R][160] = dL/d(pre-tanh decoder hidden); writes the row constants into h2b.
- *                         slabs = 8 R 160 floats, mpart = 8 R floats of scratch
+ *                         slabs = 16 R 160 floats, mpart = 16 R floats of scratch
  *   svae_proj_nll_bwd_dw  weight-side gradient gw3 [I_rows][160], gb3 [I_rows] (after _fwd_dh of the same
- *                         batch); slabs = 8 I 160 floats; occ_off [I+1] / occ_row = target occurrences by item,
+ *                         batch); slabs = 16 I 160 floats; occ_off [I+1] / occ_row = target occurrences by item,
  *                         occ_items [I] = items by occurrence count (descending), the first nocc_long of them
  *                         with more than svae_proj_occ_long() occurrences
  * R_pad, I_pad: multiples of 64.  parts (bit mask, 3 = everything): 1 sweep kernel, 2 finish kernel -- the
- * split exists so a profiler can bracket one kernel. */
+ * split exists so a profiler can bracket one kernel.
+ * Work division: every sweep takes a schedule built ONCE per shape by svae_proj_schedule (a HOST function:
+ * nx resident rows -- R for _fwd / _fwd_dh, I for _bwd_dw -- ny streamed rows, ncu compute units; uniform = 1
+ * gives every x tile the same split count (for sweeps whose streamed operand outgrows the L2); writes 4 ints
+ * per workgroup into HOST memory `sched`, room for cap >= svae_proj_ns_max() * ceil(nx/256) workgroups; returns
+ * the workgroup count nwg, and ns_q / ns_rem: x tile j of 256 rows is split ns_q + (j < ns_rem) ways).  The
+ * caller copies the table to the device and passes it with (nwg, ns_q, ns_rem).  Scratch is sized for
+ * svae_proj_ns_max() (= 16) slabs: part 16*2*R, mpart 16*R, slabs 16*R*160 (_fwd_dh) or 16*I*160 (_bwd_dw) floats. */
 int svae_proj_nsplit(void);
+int svae_proj_ns_max(void);
+int svae_proj_schedule(int nx, int ny, int ncu, int uniform, int* sched_host, int cap, int* ns_q, int* ns_rem);
 int svae_proj_tile(void);
 int svae_proj_prep_rows(const float* h2, int R, int R_pad, void* h2b, void* h2s, void* h2tb, void* stream);
 int svae_proj_prep_items(const float* w3, const float* b3, int I, int I_pad, void* w3b, void* w3s, void* w3tb,
                          void* stream);
 int svae_proj_nll_fwd(const void* h2s, const void* w3b, const float* h2, const float* w3, const float* b3,
-                      const int* tgt, int R, int I, int K, float* part, float* nll_row, float* lse, void* stream);
+                      const int* tgt, int R, int I, int K, float* part, float* nll_row, float* lse,
+                      const int* sched, int nwg, int ns_q, int ns_rem, void* stream);
 int svae_proj_nll_fwd_dh(const void* h2s, void* h2b, const void* w3b, const void* w3tb, int I_pad, const float* h2,
                          const float* w3, const float* b3, const int* tgt, const float* w_nll, int R, int I, int K,
-                         float* slabs, float* mpart, float* nll_row, float* lse, float* dd1, int parts,
-                         void* stream);
+                         float* slabs, float* mpart, float* nll_row, float* lse, float* dd1, const int* sched,
+                         int nwg, int ns_q, int ns_rem, int parts, void* stream);
 int svae_proj_occ_long(void);
 int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad, int I, int I_rows,
                          const float* h2, const float* w_nll, const int* occ_off, const int* occ_row,
-                         const int* occ_items, int nocc_long, float* slabs, float* gw3, float* gb3, int parts,
-                         void* stream);
+                         const int* occ_items, int nocc_long, float* slabs, float* gw3, float* gb3,
+                         const int* sched, int nwg, int ns_q, int ns_rem, int parts, void* stream);
 
 /* ---- Adam with L2 weight decay on one flat buffer ----------------------------------------------------
  * Replaces optimizer.step() nb:1206 with torch.optim.Adam(weight_decay=5e-3) nb:1260-1263 (and the

@@ -40,9 +40,11 @@ SIGNATURES = {
     "svae_philox_normal": [_P, _P, _I, _ULL, _U, _P],
     "svae_proj_prep_rows": [_P, _I, _I, _P, _P, _P, _P],
     "svae_proj_prep_items": [_P, _P, _I, _I, _P, _P, _P, _P],
-    "svae_proj_nll_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
-    "svae_proj_nll_fwd_dh": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
-    "svae_proj_nll_bwd_dw": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P],
+    "svae_proj_nll_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P],
+    "svae_proj_nll_fwd_dh": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I,
+                             _I, _P],
+    "svae_proj_nll_bwd_dw": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "svae_proj_ns_max": [],
     "svae_mlp_frag_elems": [],
     "svae_mlp_prep": [_P, _P, _P, _P, _P],
     "svae_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
@@ -88,6 +90,22 @@ def call(name, *args):
     if rc != 0:
         msg = lib.svae_last_error().decode("utf-8", "replace")
         raise SvaeHipError("%s failed (rc=%d): %s" % (name, rc, msg))
+
+
+def proj_schedule(nx, ny, ncu, uniform=False):
+    """Work division of one projection sweep (svae_proj_schedule): returns (int32 numpy array [nwg, 4], ns_q, ns_rem)."""
+    import numpy as np
+    lib = load()
+    cap = lib.svae_proj_ns_max() * ((nx + 255) // 256)
+    buf = np.zeros((cap, 4), dtype=np.int32)
+    q, rem = _I(0), _I(0)
+    fn = lib.svae_proj_schedule
+    fn.argtypes = [_I, _I, _I, _I, _P, _I, _c.POINTER(_I), _c.POINTER(_I)]
+    fn.restype = _I
+    n = fn(nx, ny, ncu, int(uniform), buf.ctypes.data, cap, _c.byref(q), _c.byref(rem))
+    if n <= 0:
+        raise SvaeHipError("svae_proj_schedule failed (rc=%d): %s" % (n, lib.svae_last_error().decode("utf-8", "replace")))
+    return buf[:n].copy(), q.value, rem.value
 
 
 def ptr(t):

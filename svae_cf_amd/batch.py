@@ -26,7 +26,7 @@ class BatchPlan:
     __slots__ = ("B", "R", "Tmax", "K", "order", "lengths", "x", "tgt", "w_nll", "w_kl", "row_off",
                  "nact", "last_row", "perm", "seg_off", "seg_item", "nseg", "row_key", "seen",
                  "seen_off", "row_of", "device", "occ_off", "occ_row", "total_items", "nseg_long", "occ_items",
-                 "nocc_long")
+                 "nocc_long", "proj_sched")
 
     def to(self, device):
         for name in ("x", "tgt", "w_nll", "w_kl", "row_off", "nact", "last_row", "perm", "seg_off",
@@ -112,6 +112,7 @@ def build_plan(users, next_k, user_keys=None, device=None, pin=False, total_item
     nseg_long = int((seg_len > EMBED_LONG_ROWS).sum())
 
     p = BatchPlan()
+    p.proj_sched = {}          # engine-side cache: work division of the projection sweeps over this plan
     p.B, p.R, p.Tmax, p.K = B, R, Tmax, K
     p.order = order
     p.lengths = T

@@ -40,9 +40,14 @@
 // The sparse "-y" part of dlogits = w (n softmax - y) is applied by the finish kernels (targets are
 // <= k per row).
 //
-// Grid: 1-D, id -> (x tile = id / 8, y split = id % 8): blocks that share an XCD (id % 8) stream
-// the same eighth of Y, which then stays in that XCD's L2.  Each split writes its own fp32 slab
-// (deterministic; no atomics).
+// Grid: 1-D, one workgroup per entry of a host-built schedule (svae_proj_schedule): entry = (x tile, first
+// y tile, end y tile, slab).  The number of workgroups is a whole multiple of the CU count and x tile j is
+// split ns_j = q or q+1 ways (8..16) so that every CU gets the same number of y tiles: with a fixed 8-way
+// split the grid was 8*ceil(nx/256) workgroups, e.g. 688 on 256 CUs = 2.7 "rounds" that take as long as 3.
+// Entries are ordered so that the workgroups that share an XCD (id % 8) stream neighbouring parts of Y, which
+// then stay in that XCD's L2.  Each split writes its own fp32 slab (deterministic; no atomics).
+#include <algorithm>
+
 #include "common.h"
 
 #ifdef SV_PROJ_TIMING   // diagnostic build only (tools/proj_timing.py): phase stamps of waves 0 and 4 of block 0
@@ -59,7 +64,8 @@ constexpr int KS1 = KP / 16;       // 10 k-steps of GEMM1
 constexpr int NT2 = KP / 32;       // 5 n-tiles of GEMM2
 constexpr int BX = 256;            // x rows per workgroup
 constexpr int BY = 64;             // y rows per LDS tile
-constexpr int NSPLIT = 8;
+constexpr int NSPLIT = 8;           // nominal split count (schedule: 8..NS_MAX per x tile)
+constexpr int NS_MAX = 16;          // most slabs an x tile can have
 constexpr int C_ONE = 150, C_BH = 151, C_BL = 152, C_RH = 153, C_RL = 154, C_MH = 155, C_ML = 156;
 // LDS images of one stage, both UNPADDED and XOR-swizzled in units of 16-byte chunks (the swizzle is
 // applied to the LDS-DMA's per-lane SOURCE address; the destination is lane-linear):
@@ -86,7 +92,7 @@ struct ProjArgs {
     float* out;                 // FWD: float2 (m, l) [NSPLIT][nx];  FDH / DW: slabs [NSPLIT][nx][160]
     float* mpart;               // FDH: [NSPLIT][nx] stabiliser of each split
     int nx, ny, ldt;
-    int tiles_per_split;
+    const int4* sched;          // per workgroup: (x tile, first y tile, end y tile, slab)
 };
 
 // two fp32 -> packed bf16 pair (RNE): one v_cvt_pk_bf16_f32
@@ -108,12 +114,11 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int xt = blockIdx.x / NSPLIT, split = blockIdx.x % NSPLIT;
+    const int4 sc = a.sched[blockIdx.x];
+    const int xt = __builtin_amdgcn_readfirstlane(sc.x), split = __builtin_amdgcn_readfirstlane(sc.w);
     const int x0 = xt * BX + wave * 32;
-    const int ntiles = (a.ny + BY - 1) / BY;
-    const int t_begin = split * a.tiles_per_split;
-    int t_end = t_begin + a.tiles_per_split;
-    if (t_end > ntiles) t_end = ntiles;
+    const int t_begin = __builtin_amdgcn_readfirstlane(sc.y);
+    const int t_end = __builtin_amdgcn_readfirstlane(sc.z);
 
     // resident X fragments: lane (col = li -> x, half lh) element j = X[x][16 s + 8 lh + j]
     const int x = x0 + li;
@@ -474,12 +479,13 @@ __global__ void proj_prep_kernel(const float* __restrict__ src, const float* __r
 __global__ void proj_fwd_finish_kernel(const float2* __restrict__ part, const float* __restrict__ h2,
                                        const float* __restrict__ w3, const float* __restrict__ b3,
                                        const int* __restrict__ tgt, int R, int K, float* __restrict__ nll_row,
-                                       float* __restrict__ lse_out) {
+                                       float* __restrict__ lse_out, int ns_q, int ns_rem) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= R) return;
+    const int ns = ns_q + ((row / BX) < ns_rem ? 1 : 0);
     float m = NEG_BIG, l = 0.f;
-    if (lane < NSPLIT) {
+    if (lane < ns) {
         const float2 p = part[(size_t)lane * R + row];
         m = p.x; l = p.y;
     }
@@ -511,24 +517,34 @@ __global__ void proj_fdh_finish_kernel(const float* __restrict__ slabs, const fl
                                        const float* __restrict__ b3, const int* __restrict__ tgt,
                                        const float* __restrict__ w_nll, int R, int K, float* __restrict__ dd1,
                                        float* __restrict__ nll_row, float* __restrict__ lse_out,
-                                       unsigned short* __restrict__ h2b) {
+                                       unsigned short* __restrict__ h2b, int ns_q, int ns_rem) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= R) return;
     const int ln = lane < KP / 4 ? lane : 0;
-    float ms[NSPLIT];
+    const int ns = ns_q + ((row / BX) < ns_rem ? 1 : 0);     // wave-uniform
+    float ms[NS_MAX];
     float M = NEG_BIG;
 #pragma unroll
-    for (int z = 0; z < NSPLIT; ++z) {
-        ms[z] = mpart[(size_t)z * R + row];
+    for (int z = 0; z < NS_MAX; ++z) {
+        ms[z] = z < ns ? mpart[(size_t)z * R + row] : NEG_BIG;
         M = fmaxf(M, ms[z]);
     }
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int z = 0; z < NSPLIT; ++z) {
-        const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * R + row) * KP)[ln];
-        const float f = exp2f(ms[z] - M);
-        u.x += f * v.x; u.y += f * v.y; u.z += f * v.z; u.w += f * v.w;
+    for (int z0 = 0; z0 < NS_MAX; z0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int z = z0 + j < ns ? z0 + j : 0;
+            v[j] = reinterpret_cast<const float4*>(slabs + ((size_t)z * R + row) * KP)[ln];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = z0 + j < ns ? exp2f(ms[z0 + j] - M) : 0.f;     // fixed order: reproducible
+            u.x += f * v[j].x; u.y += f * v[j].y; u.z += f * v[j].z; u.w += f * v[j].w;
+        }
+        if (ns <= 8) break;
     }
     const float l = __shfl(u.w, C_MH / 4, 64);            // column 155 = sum of P
     const float lse2 = M + log2f(l);
@@ -621,7 +637,8 @@ __global__ __launch_bounds__(64 * DWL_WAVES) void proj_dw_finish_long_kernel(con
                                                                   const int* __restrict__ occ_off,
                                                                   const int* __restrict__ occ_row,
                                                                   const int* __restrict__ occ_items,
-                                                                  float* __restrict__ gw3, float* __restrict__ gb3, int I) {
+                                                                  float* __restrict__ gw3, float* __restrict__ gb3, int I,
+                                                                  int ns_q, int ns_rem) {
     __shared__ float4 red[DWL_WAVES][KP / 4];
     __shared__ float wred[DWL_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -630,7 +647,8 @@ __global__ __launch_bounds__(64 * DWL_WAVES) void proj_dw_finish_long_kernel(con
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float wsum = 0.f;
     if (wave == 0) {
-        for (int z = 0; z < NSPLIT; ++z) {
+        const int ns = ns_q + ((it / BX) < ns_rem ? 1 : 0);
+        for (int z = 0; z < ns; ++z) {
             const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * I + it) * KP)[ln];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -658,7 +676,8 @@ __global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __rest
                                                              const int* __restrict__ occ_off,
                                                              const int* __restrict__ occ_row,
                                                              const int* __restrict__ occ_items, float* __restrict__ gw3,
-                                                             float* __restrict__ gb3, int nlong, int I, int I_rows) {
+                                                             float* __restrict__ gb3, int nlong, int I, int I_rows,
+                                                             int ns_q, int ns_rem) {
     const int lane = threadIdx.x & 63;
     const int j = nlong + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= I_rows || lane >= KP / 4) return;
@@ -670,27 +689,33 @@ __global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __rest
     const int it = occ_items[j];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float wsum = 0.f;
+    const int ns = ns_q + ((it / BX) < ns_rem ? 1 : 0);      // wave-uniform
 #pragma unroll
-    for (int z = 0; z < NSPLIT; ++z) {
-        const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * I + it) * KP)[lane];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int z0 = 0; z0 < NS_MAX; z0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int z = z0 + j < ns ? z0 + j : 0;
+            v[j] = reinterpret_cast<const float4*>(slabs + ((size_t)z * I + it) * KP)[lane];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (z0 + j < ns) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+        if (ns <= 8) break;
     }
     dw_occ_sum(h2, w_nll, occ_row, occ_off[it], occ_off[it + 1], 0, 1, lane, s, wsum);
     dw_write_row(s, wsum, it, lane, gw3, gb3);
 }
 
 template <int MODE>
-int launch_proj(ProjArgs a, hipStream_t st) {
+int launch_proj(ProjArgs a, int nwg, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)proj_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return svae_fail((int)e, "svae_proj: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    const int ntiles = (a.ny + BY - 1) / BY;
-    a.tiles_per_split = (ntiles + NSPLIT - 1) / NSPLIT;
-    const int xt = (a.nx + BX - 1) / BX;
-    hipLaunchKernelGGL((proj_kernel<MODE>), dim3(xt * NSPLIT), dim3(512), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((proj_kernel<MODE>), dim3(nwg), dim3(512), LDS_BYTES, st, a);
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -706,6 +731,68 @@ extern "C" int svae_debug_proj_blocks(unsigned long long* out) {
 }
 #endif
 extern "C" int svae_proj_nsplit(void) { return NSPLIT; }
+extern "C" int svae_proj_ns_max(void) { return NS_MAX; }
+
+// Work division of one projection sweep (HOST function, no GPU work): nx resident rows in x tiles of 256, ny
+// streamed rows in y tiles of 64, ncu compute units.  uniform = 0: the workgroup count is the whole multiple of
+// ncu that the nominal 8-way split rounds up to; x tile j gets ns_j = q + (j < rem) splits (capped at 16 and at
+// the number of y tiles), split s of it the y tiles [s nt / ns_j, (s+1) nt / ns_j).  uniform = 1: see below.  sched (host memory, 4 ints per
+// workgroup, room for cap workgroups; cap >= 16 * ceil(nx/256) always suffices) receives (x tile, first y tile,
+// end y tile, slab) in launch order: sorted by where the split starts in Y and dealt to the XCDs (id % 8) in
+// contiguous runs, so the workgroups resident on one XCD at a time stream neighbouring parts of Y.
+// Returns the number of workgroups (> 0) or a negative error; *ns_q, *ns_rem as above.
+extern "C" int svae_proj_schedule(int nx, int ny, int ncu, int uniform, int* sched, int cap, int* ns_q, int* ns_rem) {
+    SV_CHECK_ARG(nx > 0 && ny > 0 && ncu > 0 && sched && ns_q && ns_rem, "svae_proj_schedule: bad arguments");
+    const int xt = (nx + BX - 1) / BX, nt = (ny + BY - 1) / BY;
+    const int lim = nt < NS_MAX ? nt : NS_MAX;
+    long long W;
+    int q, rem = 0;
+    if (uniform) {
+        // every x tile split the same number of ways (the nominal 8, or uniform - 1 when uniform > 1): all
+        // workgroups the same length, so the rounds stay aligned and the workgroups of an XCD walk Y in lockstep.
+        // Needed when a split's part of Y (40 KiB per y tile) does not fit the XCD's 4 MiB L2: a workgroup that
+        // starts late then re-fetches it from HBM -- measured on the weight-gradient sweep: +16 % with mixed split
+        // counts at 51k rows.  Other split counts measured there (ML-20M shape, beside the GRU's BPTT on 64 CUs):
+        // 3: +31 %, 4: +10 %, 6: +12 %, 9: +10 %, 12: +10 %, 16: +15 % (more slabs, or workgroups too long to pack).
+        q = uniform > 1 ? uniform - 1 : NSPLIT;
+        if (q > lim) q = lim;
+        W = (long long)q * xt;
+    } else {
+        const long long nominal = (long long)NSPLIT * xt;
+        const long long rounds = (nominal + ncu - 1) / ncu;
+        W = rounds * ncu;
+        q = (int)(W / xt), rem = (int)(W % xt);
+        if (q >= lim) { q = lim; rem = 0; }
+        W = (long long)q * xt + rem;
+    }
+    SV_CHECK_ARG(W <= cap, "svae_proj_schedule: schedule of %lld workgroups does not fit cap %d", W, cap);
+    // sort key: start of the split as a fraction of Y, s / ns_j, compared exactly as s * ns_other
+    struct Ent { int j, s, ns; };
+    Ent* e = new Ent[W];
+    long long n = 0;
+    for (int j = 0; j < xt; ++j) {
+        const int ns = q + (j < rem ? 1 : 0);
+        for (int s2 = 0; s2 < ns; ++s2) e[n++] = Ent{j, s2, ns};
+    }
+    std::stable_sort(e, e + n, [](const Ent& a, const Ent& b) {
+        const long long l = (long long)a.s * b.ns, r = (long long)b.s * a.ns;
+        return l != r ? l < r : a.j < b.j;
+    });
+    long long p = 0;
+    for (int c = 0; c < 8; ++c)
+        for (long long id = c; id < n; id += 8, ++p) {
+            const Ent& t = e[p];
+            int* o = sched + 4 * id;
+            o[0] = t.j;
+            o[1] = (int)((long long)t.s * nt / t.ns);
+            o[2] = (int)((long long)(t.s + 1) * nt / t.ns);
+            o[3] = t.s;
+        }
+    delete[] e;
+    *ns_q = q;
+    *ns_rem = rem;
+    return (int)n;
+}
 extern "C" int svae_proj_tile(void) { return BY; }
 extern "C" int svae_proj_occ_long(void) { return OCC_LONG; }
 
@@ -731,17 +818,26 @@ extern "C" int svae_proj_prep_items(const float* w3, const float* b3, int I, int
     return 0;
 }
 
+// a schedule (svae_proj_schedule) must cover every x tile of nx rows exactly ns_j times: cheap consistency check
+// of the three numbers the caller hands back (a stale schedule would leave slabs unwritten)
+static bool sched_ok(int nx, int nwg, int ns_q, int ns_rem) {
+    const int xt = (nx + BX - 1) / BX;
+    return ns_q >= 1 && ns_q <= NS_MAX && ns_rem >= 0 && ns_rem < xt && ns_q + (ns_rem > 0) <= NS_MAX &&
+           (long long)ns_q * xt + ns_rem == nwg;
+}
+
 // Reference interface replaced: Decoder.linear2 + F.log_softmax + likelihood of VAELoss.forward
 // (nb:710, nb:802-808), loss only (scoring).  part = float2 [8][R] scratch.  Outputs nll_row[R], lse[R].
 extern "C" int svae_proj_nll_fwd(const void* h2s, const void* w3b, const float* h2, const float* w3, const float* b3,
                                  const int* tgt, int R, int I, int K, float* part, float* nll_row, float* lse,
-                                 void* stream) {
-    SV_CHECK_ARG(h2s && w3b && h2 && w3 && b3 && tgt && part && nll_row && lse, "svae_proj_nll_fwd: null pointer");
+                                 const int* sched, int nwg, int ns_q, int ns_rem, void* stream) {
+    SV_CHECK_ARG(h2s && w3b && h2 && w3 && b3 && tgt && part && nll_row && lse && sched, "svae_proj_nll_fwd: null pointer");
     SV_CHECK_ARG(R > 0 && I > 0 && K >= 1, "svae_proj_nll_fwd: bad shape");
-    ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, nullptr, part, nullptr, R, I, 0, 0};
-    if (int e = launch_proj<MODE_FWD>(a, (hipStream_t)stream)) return e;
+    SV_CHECK_ARG(sched_ok(R, nwg, ns_q, ns_rem), "svae_proj_nll_fwd: schedule does not belong to R = %d", R);
+    ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, nullptr, part, nullptr, R, I, 0, (const int4*)sched};
+    if (int e = launch_proj<MODE_FWD>(a, nwg, (hipStream_t)stream)) return e;
     hipLaunchKernelGGL(proj_fwd_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const float2*)part, h2, w3, b3, tgt, R, K, nll_row, lse);
+                       (const float2*)part, h2, w3, b3, tgt, R, K, nll_row, lse, ns_q, ns_rem);
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -753,20 +849,22 @@ extern "C" int svae_proj_nll_fwd(const void* h2s, const void* w3b, const float* 
 extern "C" int svae_proj_nll_fwd_dh(const void* h2s, void* h2b, const void* w3b, const void* w3tb, int I_pad,
                                     const float* h2, const float* w3, const float* b3, const int* tgt,
                                     const float* w_nll, int R, int I, int K, float* slabs, float* mpart,
-                                    float* nll_row, float* lse, float* dd1, int parts, void* stream) {
+                                    float* nll_row, float* lse, float* dd1, const int* sched, int nwg, int ns_q,
+                                    int ns_rem, int parts, void* stream) {
     SV_CHECK_ARG(h2s && h2b && w3b && w3tb && h2 && w3 && b3 && tgt && w_nll && slabs && mpart && nll_row && lse && dd1,
                  "svae_proj_nll_fwd_dh: null pointer");
     SV_CHECK_ARG(R > 0 && I > 0 && K >= 1 && I_pad >= I && (I_pad % BY) == 0 && parts > 0 && parts < 4,
                  "svae_proj_nll_fwd_dh: bad shape");
+    SV_CHECK_ARG(sched && sched_ok(R, nwg, ns_q, ns_rem), "svae_proj_nll_fwd_dh: schedule does not belong to R = %d", R);
     hipStream_t st = (hipStream_t)stream;
     if (parts & 1) {
         ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, (const unsigned short*)w3tb, slabs, mpart,
-                   R, I, I_pad, 0};
-        if (int e = launch_proj<MODE_FDH>(a, st)) return e;
+                   R, I, I_pad, (const int4*)sched};
+        if (int e = launch_proj<MODE_FDH>(a, nwg, st)) return e;
     }
     if (parts & 2) {
         hipLaunchKernelGGL(proj_fdh_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, st, slabs, mpart, h2, w3, b3, tgt,
-                           w_nll, R, K, dd1, nll_row, lse, (unsigned short*)h2b);
+                           w_nll, R, K, dd1, nll_row, lse, (unsigned short*)h2b, ns_q, ns_rem);
         SV_LAUNCH_CHECK();
     }
     return 0;
@@ -780,24 +878,26 @@ extern "C" int svae_proj_nll_fwd_dh(const void* h2s, void* h2b, const void* w3b,
 extern "C" int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad,
                                     int I, int I_rows, const float* h2, const float* w_nll, const int* occ_off,
                                     const int* occ_row, const int* occ_items, int nocc_long, float* slabs, float* gw3,
-                                    float* gb3, int parts, void* stream) {
+                                    float* gb3, const int* sched, int nwg, int ns_q, int ns_rem, int parts,
+                                    void* stream) {
     SV_CHECK_ARG(w3s && h2b && h2tb && h2 && w_nll && occ_off && occ_row && occ_items && slabs && gw3 && gb3,
                  "svae_proj_nll_bwd_dw: null pointer");
     SV_CHECK_ARG(nocc_long >= 0 && nocc_long <= I, "svae_proj_nll_bwd_dw: bad nocc_long");
     SV_CHECK_ARG(R > 0 && I > 0 && I_rows >= I && R_pad >= R && (R_pad % BY) == 0 && parts > 0 && parts < 4,
                  "svae_proj_nll_bwd_dw: bad shape");
+    SV_CHECK_ARG(sched && sched_ok(I, nwg, ns_q, ns_rem), "svae_proj_nll_bwd_dw: schedule does not belong to I = %d", I);
     hipStream_t st = (hipStream_t)stream;
     if (parts & 1) {
         ProjArgs a{(const unsigned short*)w3s, (const unsigned short*)h2b, (const unsigned short*)h2tb, slabs, nullptr,
-                   I, R, R_pad, 0};
-        if (int e = launch_proj<MODE_DW>(a, st)) return e;
+                   I, R, R_pad, (const int4*)sched};
+        if (int e = launch_proj<MODE_DW>(a, nwg, st)) return e;
     }
     if (parts & 2) {
         if (nocc_long > 0)
             hipLaunchKernelGGL(proj_dw_finish_long_kernel, dim3(nocc_long), dim3(64 * DWL_WAVES), 0, st, slabs, h2, w_nll, occ_off,
-                               occ_row, occ_items, gw3, gb3, I);
+                               occ_row, occ_items, gw3, gb3, I, ns_q, ns_rem);
         hipLaunchKernelGGL(proj_dw_finish_kernel, dim3((I_rows - nocc_long + 3) / 4), dim3(256), 0, st, slabs, h2, w_nll,
-                           occ_off, occ_row, occ_items, gw3, gb3, nocc_long, I, I_rows);
+                           occ_off, occ_row, occ_items, gw3, gb3, nocc_long, I, I_rows, ns_q, ns_rem);
         SV_LAUNCH_CHECK();
     }
     return 0;

@@ -33,6 +33,7 @@ class SVAEEngine:
         self.device = torch.device(device)
         with torch.cuda.device(self.device):
             _lib.call("svae_check_device")
+        self._ncu = int(os.environ.get("SVAE_PROJ_CUS", torch.cuda.get_device_properties(self.device).multi_processor_count))
         self.layout = ParamLayout(total_items)
         self.I, self.IP = self.layout.I, self.layout.IP
         self.prec = prec
@@ -56,9 +57,9 @@ class SVAEEngine:
         # latency bound) stays on the caller's stream, the decoder-side weight gradients (whole-GPU kernels that
         # nothing downstream waits for) go to a side stream and fill the CUs the recurrence leaves idle.
         self.overlap = True
-        self._side = None
+        self._sides = []
         self._side_for = None
-        self.side_stream_info = None
+        self.side_stream_info = []
         self.colparts = torch.zeros(64 * max(self.IP, G), **f32)
         self._plan = None
         self._anneal = 0.0
@@ -71,6 +72,7 @@ class SVAEEngine:
         self._prepped_grad = False
         self._dtmp_extra = None
         self.grad_sync = None          # dist.GradSync for data parallel runs
+        self.event_pool = []
         self.prof = None               # dict tag -> list of (start, end) torch.cuda.Event pairs
 
     # ------------------------------------------------------------------ parameters
@@ -113,10 +115,11 @@ class SVAEEngine:
             self.ws["h2b"] = torch.zeros(capp * DP, **bf)
             self.ws["h2s"] = torch.zeros(capp * DP, **bf)
             self.ws["h2tb"] = torch.zeros(DP * capp, **bf)
-            self.ws["part"] = torch.zeros(8 * capp * 2, **f32)
-            self.ws["mpart"] = torch.zeros(8 * capp, **f32)
-            self.ws["pslabs"] = torch.empty(8 * capp * DP, **f32)
-            self.ws["pslabs_side"] = torch.empty(8 * self.IPAD * DP, **f32)
+            nsm = _lib.load().svae_proj_ns_max()
+            self.ws["part"] = torch.zeros(nsm * capp * 2, **f32)
+            self.ws["mpart"] = torch.zeros(nsm * capp, **f32)
+            self.ws["pslabs"] = torch.empty(nsm * capp * DP, **f32)
+            self.ws["pslabs_side"] = torch.empty(nsm * self.IPAD * DP, **f32)
             if self.w3b is None:
                 self.mlp_frags = torch.zeros(_lib.load().svae_mlp_frag_elems(), **bf)
                 self.w3b = torch.zeros(self.IPAD * DP, **bf)
@@ -134,17 +137,21 @@ class SVAEEngine:
                   _lib.ptr(colsum), M, N, K, lda, ldb, ldc, ldaux, al, bl, act, self.prec, nsplit, slab_stride, _stream())
         self._toc(tag, ev)
 
+    def _event(self):
+        # events are taken from a pool filled outside the timed region (creating one costs ~10 us of host time)
+        return self.event_pool.pop() if self.event_pool else torch.cuda.Event(enable_timing=True)
+
     def _tic(self, tag):
         if self.prof is None or tag not in self.prof:
             return None
-        ev = torch.cuda.Event(enable_timing=True)
+        ev = self._event()
         ev.record()
         return ev
 
     def _toc(self, tag, ev):
         if ev is None:
             return
-        end = torch.cuda.Event(enable_timing=True)
+        end = self._event()
         end.record()
         self.prof[tag].append((ev, end))
 
@@ -152,41 +159,47 @@ class SVAEEngine:
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(i)
 
-    def _side_stream(self):
-        """The stream of the overlapped work.  HIP maps streams onto a few hardware queues (4 per process here)
-        and two streams that share a queue run IN ORDER: a side stream that landed on the caller's queue
-        serialises the whole backward (seen with the process group created before the engine: 1.17 -> 1.54 ms
-        per step).  So the stream is chosen by measurement: candidates are tried until one runs a spin kernel
-        concurrently with the caller's stream."""
+    def _side_stream(self, which=0):
+        """Stream `which` (0, 1) of the overlapped work.  HIP maps streams onto a few hardware queues (4 per
+        process here) and two streams that share a queue run IN ORDER: a side stream that landed on the caller's
+        queue serialises the whole backward (seen with the process group created before the engine: 1.17 -> 1.54 ms
+        per step).  So the streams are chosen by measurement: candidates are tried until one runs a spin kernel
+        concurrently with the caller's stream (and with the side streams chosen before it)."""
         cur = torch.cuda.current_stream()
-        if self._side is not None and self._side_for == cur.cuda_stream:
-            return self._side
-        self._side, self._side_for = self._pick_concurrent_stream(cur), cur.cuda_stream
-        return self._side
+        if self._side_for != cur.cuda_stream:
+            self._sides, self._side_for, self.side_stream_info = [], cur.cuda_stream, []
+        while len(self._sides) <= which:
+            self._sides.append(self._pick_concurrent_stream([cur] + self._sides))
+        return self._sides[which]
 
-    def _pick_concurrent_stream(self, cur, tries=8, usec=200):
-        def spin_pair(other):
+    def _pick_concurrent_stream(self, others, tries=8, usec=200):
+        """A new stream that runs concurrently with every stream of `others` (others[0] = the caller's)."""
+        cur = others[0]
+
+        def spin_all(cand):
             torch.cuda.synchronize(self.device)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(cur)
-            other.wait_event(e0)
-            _lib.call("svae_spin", usec, cur.cuda_stream)
-            _lib.call("svae_spin", usec, other.cuda_stream)
-            cur.wait_stream(other)
+            for o in others[1:] + [cand]:
+                o.wait_event(e0)
+            for o in others + [cand]:
+                _lib.call("svae_spin", usec, o.cuda_stream)
+            for o in others[1:] + [cand]:
+                cur.wait_stream(o)
             e1.record(cur)
             e1.synchronize()
             return e0.elapsed_time(e1) * 1e3
         cands = [torch.cuda.Stream(device=self.device) for _ in range(tries)]
         times = []
         for c in cands:
-            spin_pair(c)                      # first use of a stream creates its queue: not timed
-            t = min(spin_pair(c), spin_pair(c))
+            spin_all(c)                       # first use of a stream creates its queue: not timed
+            t = min(spin_all(c), spin_all(c))
             times.append(t)
             if t < 1.5 * usec:
-                self.side_stream_info = dict(tried=len(times), pair_us=t, concurrent=True)
+                self.side_stream_info.append(dict(tried=len(times), all_us=t, concurrent=True))
                 return c
         best = min(range(tries), key=lambda i: times[i])
-        self.side_stream_info = dict(tried=tries, pair_us=times[best], concurrent=False)
+        self.side_stream_info.append(dict(tried=tries, all_us=times[best], concurrent=False))
         return cands[best]
 
     def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx, slabs=None):
@@ -233,6 +246,7 @@ class SVAEEngine:
         w, st = self.ws, _stream()
         self._plan, self._anneal = plan, float(anneal)
         params_ready = None
+        eps_done = False
         if self.fused and self.overlap:
             # everything that depends on the parameters only (bf16 operand copies, weight fragments, W_hh^T, the
             # zero fill of the embedding gradient) runs on the side stream beside the embedding / GRU kernels
@@ -240,6 +254,10 @@ class SVAEEngine:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._param_prep(want_grad)
+                if eps is None:               # the noise depends on the plan and the step only
+                    _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
+                              int(step) & 0xFFFFFFFF, _stream())
+                    eps_done = True
                 params_ready = torch.cuda.Event()
                 params_ready.record()
         _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
@@ -255,7 +273,7 @@ class SVAEEngine:
             if eps.numel() != R * L:
                 raise ValueError("eps must have %d x %d elements" % (R, L))
             w["eps"][:R * L].copy_(eps.reshape(-1))
-        else:
+        elif not eps_done:
             _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
                       int(step) & 0xFFFFFFFF, st)
         if self.fused:
@@ -288,13 +306,13 @@ class SVAEEngine:
                         self.IPAD, w["d1"].data_ptr(), self.P("decoder.linear2.weight").data_ptr(),
                         self.P("decoder.linear2.bias").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
                         R, self.I, plan.K, w["pslabs"].data_ptr(), w["mpart"].data_ptr(), w["nll_row"].data_ptr(),
-                        w["lse"].data_ptr(), w["dd1"].data_ptr())
+                        w["lse"].data_ptr(), w["dd1"].data_ptr()) + self._proj_sched(plan, "rows")
                 self._split_call("svae_proj_nll_fwd_dh", args, ((1, "proj_fdh_fused"), (2, "proj_fdh_finish")))
             else:
                 _lib.call("svae_proj_nll_fwd", w["h2s"].data_ptr(), self.w3b.data_ptr(), w["d1"].data_ptr(),
                           self.P("decoder.linear2.weight").data_ptr(), self.P("decoder.linear2.bias").data_ptr(),
                           plan.tgt.data_ptr(), R, self.I, plan.K, w["part"].data_ptr(), w["nll_row"].data_ptr(),
-                          w["lse"].data_ptr(), st)
+                          w["lse"].data_ptr(), *self._proj_sched(plan, "rows"), st)
             self._fused_grad = bool(want_grad)
             if defer_loss and want_grad and self.overlap:
                 # nothing in backward reads the scalar loss: reduce it on the side stream (joined at the end of backward)
@@ -333,6 +351,22 @@ class SVAEEngine:
             ev = self._tic(tag)
             _lib.call(name, *args, bit, _stream())
             self._toc(tag, ev)
+
+    def _proj_sched(self, plan, side):
+        """(device table, nwg, ns_q, ns_rem) of a projection sweep over this plan: 'rows' = rows resident, items
+        streamed (forward / dL/dh sweep), 'items' = the weight-gradient sweep.  Built once per plan and engine."""
+        key = (side, self.I, self._ncu)
+        cache = plan.proj_sched
+        if key not in cache:
+            nx, ny = (plan.R, self.I) if side == "rows" else (self.I, plan.R)
+            uni = 0
+            if side == "items":
+                fq = int(os.environ.get("SVAE_DW_Q", "0"))
+                uni = 1 + fq if fq > 0 else 1
+            tab, q, rem = _lib.proj_schedule(nx, ny, int(os.environ.get("SVAE_DW_CUS", self._ncu)) if uni else self._ncu, uniform=uni)
+            cache[key] = (torch.from_numpy(tab).to(self.device), int(tab.shape[0]), q, rem)
+        t, n, q, rem = cache[key]
+        return (t.data_ptr(), n, q, rem)
 
     def _param_prep(self, want_grad):
         """Per-step work that depends on the parameters only (they change at every optimizer step)."""
@@ -400,7 +434,7 @@ class SVAEEngine:
                         w["d1"].data_ptr(), plan.w_nll.data_ptr(), plan.occ_off.data_ptr(), plan.occ_row.data_ptr(),
                         plan.occ_items.data_ptr(), plan.nocc_long, slabs.data_ptr(),
                         self.Gv("decoder.linear2.weight").data_ptr(),
-                        self.Gv("decoder.linear2.bias").data_ptr())
+                        self.Gv("decoder.linear2.bias").data_ptr()) + self._proj_sched(plan, "items")
                 self._split_call("svae_proj_nll_bwd_dw", args, ((1, "proj_dw_fused"), (2, "proj_dw_finish")))
 
             if self.overlap:
@@ -460,9 +494,17 @@ class SVAEEngine:
                 proj_dw(w["pslabs_side"])
                 self._bucket(0)
                 decoder_side_wgrads(self.slabs_side)
-        self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
-        self._wgrad(w["dgi"], w["emb"], "gru.weight_ih_l0", R, G, E, G, E)
-        self._bucket(2)
+        side2 = None
+        if side is not None and os.environ.get("SVAE_SIDE2", "0") == "1":
+            # (experiment, off: the GRU's two weight gradients on a second side stream beside dL/demb -> scatter-add.
+            # Measured 2.5 % SLOWER, 1.153 vs 1.123 ms per step: the tail of backward is short of bandwidth, not of
+            # parallelism, and the weight-gradient sweep on the first side stream loses more than the chain gains.)
+            side2 = self._side_stream(1)
+            side2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side2 if side2 is not None else torch.cuda.current_stream()):
+            self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
+            self._wgrad(w["dgi"], w["emb"], "gru.weight_ih_l0", R, G, E, G, E)
+            self._bucket(2)
         self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
         # embedding: dense gradient, zero + deterministic segmented scatter-add
         ge = self.Gv("item_embed.weight")
@@ -474,6 +516,8 @@ class SVAEEngine:
         self._bucket(3)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+            if side2 is not None:
+                torch.cuda.current_stream().wait_stream(side2)
 
     # ------------------------------------------------------------------ dense (notebook) surface
     def dense_loss(self, logits, mu, ls, tgt, anneal, batch_size=1.0):
