@@ -168,6 +168,9 @@ int svae_transpose(const float* in, float* out, int rows, int cols, void* stream
 int svae_gather_rows(const float* in, const int* idx, float* out, int nrows, int ld_in, int ld_out, int n,
                      void* stream);
 
+/* Zero fill of nbytes at p on the stream (model.zero_grad() nb:1197 for the embedding gradient, the only gradient
+ * that is accumulated into rather than written). */
+int svae_zero(void* p, long long nbytes, void* stream);
 /* One workgroup busy for usec microseconds: lets the host test whether two streams run concurrently (streams
  * that share a hardware queue do not).  No counterpart in the reference (single stream there). */
 int svae_spin(int usec, void* stream);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "svae_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "svae_mlp_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "svae_spin": [_I, _P],
+    "svae_zero": [_P, _LL, _P],
     "svae_proj_nsplit": [],
     "svae_proj_tile": [],
     "svae_check_device": [],
@@ -84,11 +85,16 @@ def load():
     return lib
 
 
+_fns = {}
+
+
 def call(name, *args):
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
-        msg = lib.svae_last_error().decode("utf-8", "replace")
+        msg = load().svae_last_error().decode("utf-8", "replace")
         raise SvaeHipError("%s failed (rc=%d): %s" % (name, rc, msg))
 
 

@@ -546,3 +546,11 @@ extern "C" int svae_spin(int usec, void* stream) {
     SV_LAUNCH_CHECK();
     return 0;
 }
+
+// Zero fill (replaces the zero_grad pair nb:1197-1198 for the one gradient that is accumulated into, the embedding table's).
+extern "C" int svae_zero(void* p, long long nbytes, void* stream) {
+    SV_CHECK_ARG(p && nbytes > 0, "svae_zero: bad arguments");
+    hipError_t e = hipMemsetAsync(p, 0, (size_t)nbytes, (hipStream_t)stream);
+    if (e != hipSuccess) return svae_fail((int)e, "svae_zero: %s", hipGetErrorString(e));
+    return 0;
+}

@@ -20,8 +20,37 @@ PREC_FP32 = 0
 PREC_BF16 = 1
 
 
+# Launch stream of the kernels.  torch.cuda.current_stream() costs ~8 us of host time (device-index and
+# environment look-ups) and the step asked for it 33 times; forward / backward / adam_step now ask once and pin
+# the raw pointer here, `_Launch` switches it (and, only when torch ops or collectives must follow, torch's own
+# current stream) for the side-stream sections.
+_PINNED = [None]
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    p = _PINNED[0]
+    return p if p is not None else torch.cuda.current_stream().cuda_stream
+
+
+class _Launch:
+    """with _Launch(stream, also_torch): kernels launched through ``_stream()`` go to `stream`."""
+
+    def __init__(self, stream, also_torch=False):
+        self.stream = stream
+        self.ctx = torch.cuda.stream(stream) if also_torch else None
+
+    def __enter__(self):
+        self.prev = _PINNED[0]
+        _PINNED[0] = self.stream.cuda_stream
+        if self.ctx is not None:
+            self.ctx.__enter__()
+        return self.stream
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        _PINNED[0] = self.prev
+        return False
 
 
 class SVAEEngine:
@@ -46,6 +75,8 @@ class SVAEEngine:
         self.exp_avg = torch.zeros(n, **f32)
         self.exp_avg_sq = torch.zeros(n, **f32)
         self.step_count = 0
+        self._pviews, self._gviews = {}, {}
+        self._gbase = self.grads.data_ptr()
         self.whh_t = torch.zeros(HP * G, **f32)
         self.loss_out = torch.zeros(4, **f32)
         self.cap = 0
@@ -71,16 +102,28 @@ class SVAEEngine:
         self._fused_grad = False
         self._prepped_grad = False
         self._dtmp_extra = None
+        self._loss_deferred = False
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.event_pool = []
         self.prof = None               # dict tag -> list of (start, end) torch.cuda.Event pairs
 
     # ------------------------------------------------------------------ parameters
     def P(self, name):
-        return self.layout.view(self.params, name)
+        v = self._pviews.get(name)
+        if v is None:
+            v = self._pviews[name] = self.layout.view(self.params, name)
+        return v
 
     def Gv(self, name):
-        return self.layout.view(self.grads, name)
+        v = self._gviews.get(name)
+        if v is None:
+            v = self._gviews[name] = self.layout.view(self.grads, name)
+        return v
+
+    def _torch_ctx(self):
+        """Side-stream sections must also switch torch's current stream when events are recorded for profiling or
+        collectives are issued from inside them; otherwise the raw launch pointer is enough (and much cheaper)."""
+        return self.prof is not None or self.grad_sync is not None
 
     def load_state_dict(self, sd):
         self.layout.pack(sd, self.params)
@@ -159,13 +202,13 @@ class SVAEEngine:
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(i)
 
-    def _side_stream(self, which=0):
+    def _side_stream(self, which=0, cur=None):
         """Stream `which` (0, 1) of the overlapped work.  HIP maps streams onto a few hardware queues (4 per
         process here) and two streams that share a queue run IN ORDER: a side stream that landed on the caller's
         queue serialises the whole backward (seen with the process group created before the engine: 1.17 -> 1.54 ms
         per step).  So the streams are chosen by measurement: candidates are tried until one runs a spin kernel
         concurrently with the caller's stream (and with the side streams chosen before it)."""
-        cur = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream() if cur is None else cur
         if self._side_for != cur.cuda_stream:
             self._sides, self._side_for, self.side_stream_info = [], cur.cuda_stream, []
         while len(self._sides) <= which:
@@ -207,27 +250,28 @@ class SVAEEngine:
         gb[N] = column sums of dY (folded into the GEMM).  Split-K over rows writes one slab per split
         (weights then bias), summed in a fixed order: deterministic, no atomics.  The bias gradient sits
         right behind the weight gradient in the flat buffer (layout.py keeps them adjacent)."""
-        out = self.grads[self.layout.offset(wname):]
+        out = self._gbase + 4 * self.layout.offset(wname)
         slabs = self.slabs if slabs is None else slabs
+        sp = slabs.data_ptr()
         ns = max(1, min(self.nsplit, (R + 127) // 128))
         stride = N * K + N
         if self.prec == PREC_BF16:
             ev = self._tic("wgrad")
             if ns == 1:
-                _lib.call("svae_wgrad", dY.data_ptr(), X.data_ptr(), out.data_ptr(), out[N * K:].data_ptr(), R, N, K,
-                          ldy, ldx, 1, 0, _stream())
+                _lib.call("svae_wgrad", dY.data_ptr(), X.data_ptr(), out, out + 4 * N * K, R, N, K, ldy, ldx, 1, 0, _stream())
             else:
-                _lib.call("svae_wgrad", dY.data_ptr(), X.data_ptr(), slabs.data_ptr(), slabs[N * K:].data_ptr(), R, N, K,
-                          ldy, ldx, ns, stride, _stream())
-                _lib.call("svae_reduce_slabs", slabs.data_ptr(), out.data_ptr(), stride, ns, stride, _stream())
+                _lib.call("svae_wgrad", dY.data_ptr(), X.data_ptr(), sp, sp + 4 * N * K, R, N, K, ldy, ldx, ns, stride,
+                          _stream())
+                _lib.call("svae_reduce_slabs", sp, out, stride, ns, stride, _stream())
             self._toc("wgrad", ev)
             return
+        outv = self.grads[self.layout.offset(wname):]
         if ns == 1:
-            self._gemm(dY, X, out, N, K, R, ldy, ldx, K, 1, 1, colsum=out[N * K:])
+            self._gemm(dY, X, outv, N, K, R, ldy, ldx, K, 1, 1, colsum=outv[N * K:])
         else:
             self._gemm(dY, X, slabs, N, K, R, ldy, ldx, K, 1, 1, nsplit=ns, slab_stride=stride,
                        colsum=slabs[N * K:])
-            _lib.call("svae_reduce_slabs", slabs.data_ptr(), out.data_ptr(), stride, ns, stride, _stream())
+            _lib.call("svae_reduce_slabs", sp, out, stride, ns, stride, _stream())
 
     def _colsum(self, A, out, R, N, ld):
         nparts = max(1, min(64, (R + 127) // 128))
@@ -241,6 +285,11 @@ class SVAEEngine:
         np.random.normal draws, nb:744); otherwise Philox noise keyed by (seed, step, row_key).
         After the call ``ws['logits']`` holds the logits (want_grad=False) or dlogits (want_grad=True).
         """
+        cur = torch.cuda.current_stream()
+        with _Launch(cur):
+            return self._forward(cur, plan, anneal, eps, seed, step, want_grad, want_loss, defer_loss)
+
+    def _forward(self, cur, plan, anneal, eps, seed, step, want_grad, want_loss, defer_loss):
         R = plan.R
         self._ensure(R)
         w, st = self.ws, _stream()
@@ -250,16 +299,16 @@ class SVAEEngine:
         if self.fused and self.overlap:
             # everything that depends on the parameters only (bf16 operand copies, weight fragments, W_hh^T, the
             # zero fill of the embedding gradient) runs on the side stream beside the embedding / GRU kernels
-            side = self._side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            side = self._side_stream(cur=cur)
+            side.wait_stream(cur)
+            with _Launch(side, self._torch_ctx()):
                 self._param_prep(want_grad)
                 if eps is None:               # the noise depends on the plan and the step only
                     _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
                               int(step) & 0xFFFFFFFF, _stream())
                     eps_done = True
                 params_ready = torch.cuda.Event()
-                params_ready.record()
+                params_ready.record(side)
         _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
                   w["emb"].data_ptr(), R, self.I, st)
         self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
@@ -279,7 +328,7 @@ class SVAEEngine:
         if self.fused:
             # encoder -> (mu | log_sigma) -> z, KL -> decoder hidden in one kernel (bf16 MFMA mode)
             if params_ready is not None:
-                torch.cuda.current_stream().wait_event(params_ready)
+                cur.wait_event(params_ready)
             else:
                 self._param_prep(want_grad)
             ev = self._tic("mlp_fwd")
@@ -315,13 +364,9 @@ class SVAEEngine:
                           w["lse"].data_ptr(), *self._proj_sched(plan, "rows"), st)
             self._fused_grad = bool(want_grad)
             if defer_loss and want_grad and self.overlap:
-                # nothing in backward reads the scalar loss: reduce it on the side stream (joined at the end of backward)
-                side = self._side_stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(),
-                              plan.w_nll.data_ptr(), plan.w_kl.data_ptr(), float(anneal), R,
-                              self.loss_out.data_ptr(), _stream())
+                # nothing in backward reads the scalar loss: backward() reduces it on the side stream, behind the
+                # event that stream waits for anyway
+                self._loss_deferred = True
             else:
                 _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
                           plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
@@ -378,7 +423,8 @@ class SVAEEngine:
                   self.w3s.data_ptr(), self.w3tb.data_ptr(), st)
         if want_grad:
             _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
-            self.Gv("item_embed.weight").zero_()
+            e = self.layout.entries["item_embed.weight"]
+            _lib.call("svae_zero", self._gbase + 4 * e.offset, 4 * e.size, st)
         self._prepped_grad = bool(want_grad)
 
     def _proj_prepare(self, R):
@@ -417,6 +463,11 @@ class SVAEEngine:
         """Gradients of the batched loss w.r.t. every parameter into ``self.grads``.
 
         Expects ``forward(..., want_grad=True)`` before it (ws['logits'] holds dlogits)."""
+        cur = torch.cuda.current_stream()
+        with _Launch(cur):
+            self._backward(cur)
+
+    def _backward(self, cur):
         plan, anneal = self._plan, self._anneal
         R, I, IP = plan.R, self.I, self.IP
         w, st = self.ws, _stream()
@@ -438,7 +489,7 @@ class SVAEEngine:
                 self._split_call("svae_proj_nll_bwd_dw", args, ((1, "proj_dw_fused"), (2, "proj_dw_finish")))
 
             if self.overlap:
-                side = self._side_stream()
+                side = self._side_stream(cur=cur)
             else:
                 proj_dw(w["pslabs_side"])
                 self._bucket(0)
@@ -476,7 +527,7 @@ class SVAEEngine:
             decoder_side_wgrads(self.slabs)
         else:
             chain_done = torch.cuda.Event()
-            chain_done.record()
+            chain_done.record(cur)
         # GRU (BPTT)
         prepped = self.fused and self._prepped_grad
         if not prepped:
@@ -490,34 +541,36 @@ class SVAEEngine:
             # gated on the chain above, enqueued after the recurrence so that its few workgroups get their CUs
             # first; the weight-gradient kernels then take whatever the recurrence leaves idle
             side.wait_event(chain_done)
-            with torch.cuda.stream(side):
+            with _Launch(side, self._torch_ctx()):
+                if self._loss_deferred:
+                    _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(),
+                              plan.w_nll.data_ptr(), plan.w_kl.data_ptr(), float(anneal), R,
+                              self.loss_out.data_ptr(), _stream())
                 proj_dw(w["pslabs_side"])
                 self._bucket(0)
                 decoder_side_wgrads(self.slabs_side)
-        side2 = None
-        if side is not None and os.environ.get("SVAE_SIDE2", "0") == "1":
-            # (experiment, off: the GRU's two weight gradients on a second side stream beside dL/demb -> scatter-add.
-            # Measured 2.5 % SLOWER, 1.153 vs 1.123 ms per step: the tail of backward is short of bandwidth, not of
-            # parallelism, and the weight-gradient sweep on the first side stream loses more than the chain gains.)
-            side2 = self._side_stream(1)
-            side2.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side2 if side2 is not None else torch.cuda.current_stream()):
-            self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
-            self._wgrad(w["dgi"], w["emb"], "gru.weight_ih_l0", R, G, E, G, E)
-            self._bucket(2)
+        # Order of the tail: the embedding gradient first.  Its bucket is the largest of the step (256 I floats) and
+        # its all-reduce then runs under the GRU weight-gradient kernels; the GRU bucket that ends the step is 1.3 MB.
         self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
         # embedding: dense gradient, zero + deterministic segmented scatter-add
         ge = self.Gv("item_embed.weight")
         if not prepped:
-            ge.zero_()
+            _lib.call("svae_zero", ge.data_ptr(), 4 * ge.numel(), st)
         self._prepped_grad = False
         _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
                   plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, plan.nseg_long, 1.0, st)
         self._bucket(3)
+        # (Tried: these two on a second side stream beside dL/demb -> scatter-add.  2.5 % SLOWER, 1.153 vs 1.123 ms
+        # per step: the tail of backward is short of bandwidth, not of parallelism.)
+        self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
+        self._wgrad(w["dgi"], w["emb"], "gru.weight_ih_l0", R, G, E, G, E)
+        self._bucket(2)
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            if side2 is not None:
-                torch.cuda.current_stream().wait_stream(side2)
+            cur.wait_stream(side)
+        elif self._loss_deferred:
+            _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
+                      plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
+        self._loss_deferred = False
 
     # ------------------------------------------------------------------ dense (notebook) surface
     def dense_loss(self, logits, mu, ls, tgt, anneal, batch_size=1.0):

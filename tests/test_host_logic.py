@@ -194,6 +194,32 @@ def test_rank_batches_balanced_and_disjoint():
     assert all((a == b).all() for a, b in zip(one, ref))
 
 
+@pytest.mark.parametrize("uniform", [False, True])
+def test_proj_schedule_covers_every_tile_once(uniform):
+    """svae_proj_schedule (host function of the C-ABI library): every (x tile, y tile) pair belongs to exactly
+    one workgroup, an x tile's slabs are 0..ns_j-1, split counts are q or q+1 (uniform: all q), and the balanced
+    form launches a whole number of rounds on 256 CUs when the 16-slab cap does not bind."""
+    from svae_cf_amd import _lib
+    for nx, ny in ((21814, 20000), (20000, 21814), (300, 97), (97, 300), (2957, 20000), (50944, 20000), (257, 63), (1, 1)):
+        tab, q, rem = _lib.proj_schedule(nx, ny, 256, uniform)
+        xt, nt = (nx + 255) // 256, (ny + 63) // 64
+        cov = np.zeros((xt, nt), dtype=np.int64)
+        for j, b, e, s in tab:
+            assert 0 <= b <= e <= nt
+            cov[j, b:e] += 1
+        assert (cov == 1).all(), (nx, ny)
+        ns = np.bincount(tab[:, 0], minlength=xt)
+        assert (ns[:rem] == q + 1).all() and (ns[rem:] == q).all() and q + (rem > 0) <= _lib.load().svae_proj_ns_max()
+        for j in range(xt):
+            assert sorted(tab[tab[:, 0] == j][:, 3].tolist()) == list(range(ns[j]))
+        if uniform:
+            assert rem == 0 and q == min(8, nt)
+        elif q < min(16, nt):
+            assert len(tab) % 256 == 0
+        ln = tab[:, 2] - tab[:, 1]
+        assert ln.max() - ln.min() <= nt // q - nt // (q + 1) + 1
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
