@@ -25,6 +25,7 @@ PREC_BF16 = 1
 # the raw pointer here, `_Launch` switches it (and, only when torch ops or collectives must follow, torch's own
 # current stream) for the side-stream sections.
 _PINNED = [None]
+_PINNED_OBJ = [None]
 
 
 def _stream():
@@ -40,8 +41,8 @@ class _Launch:
         self.ctx = torch.cuda.stream(stream) if also_torch else None
 
     def __enter__(self):
-        self.prev = _PINNED[0]
-        _PINNED[0] = self.stream.cuda_stream
+        self.prev, self.prev_obj = _PINNED[0], _PINNED_OBJ[0]
+        _PINNED[0], _PINNED_OBJ[0] = self.stream.cuda_stream, self.stream
         if self.ctx is not None:
             self.ctx.__enter__()
         return self.stream
@@ -49,7 +50,7 @@ class _Launch:
     def __exit__(self, *exc):
         if self.ctx is not None:
             self.ctx.__exit__(*exc)
-        _PINNED[0] = self.prev
+        _PINNED[0], _PINNED_OBJ[0] = self.prev, self.prev_obj
         return False
 
 
@@ -103,6 +104,7 @@ class SVAEEngine:
         self._prepped_grad = False
         self._dtmp_extra = None
         self._loss_deferred = False
+        self.tail_embedding_first = os.environ.get("SVAE_TAIL", "emb") == "emb"
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.event_pool = []
         self.prof = None               # dict tag -> list of (start, end) torch.cuda.Event pairs
@@ -121,9 +123,9 @@ class SVAEEngine:
         return v
 
     def _torch_ctx(self):
-        """Side-stream sections must also switch torch's current stream when events are recorded for profiling or
-        collectives are issued from inside them; otherwise the raw launch pointer is enough (and much cheaper)."""
-        return self.prof is not None or self.grad_sync is not None
+        """Side-stream sections must also switch torch's current stream when collectives are issued from inside
+        them; otherwise the raw launch pointer is enough (and much cheaper)."""
+        return self.grad_sync is not None
 
     def load_state_dict(self, sd):
         self.layout.pack(sd, self.params)
@@ -188,14 +190,14 @@ class SVAEEngine:
         if self.prof is None or tag not in self.prof:
             return None
         ev = self._event()
-        ev.record()
+        ev.record(_PINNED_OBJ[0]) if _PINNED_OBJ[0] is not None else ev.record()
         return ev
 
     def _toc(self, tag, ev):
         if ev is None:
             return
         end = self._event()
-        end.record()
+        end.record(_PINNED_OBJ[0]) if _PINNED_OBJ[0] is not None else end.record()
         self.prof[tag].append((ev, end))
 
     def _bucket(self, i):
@@ -521,7 +523,6 @@ class SVAEEngine:
             self._wgrad(w["dd1"], w["z"], "decoder.linear1.weight", R, DP, L, DP, L, slabs=slabs)
             self._wgrad(w["dtmp"], w["enc"], "linear1.weight", R, 2 * L, DP, 2 * L, DP, slabs=slabs)
             self._wgrad(w["denc"], w["hs"], "encoder.linear1.weight", R, DP, HP, DP, HP, slabs=slabs)
-            self._bucket(1)
 
         if side is None:
             decoder_side_wgrads(self.slabs)
@@ -551,26 +552,36 @@ class SVAEEngine:
                 decoder_side_wgrads(self.slabs_side)
         # Order of the tail: the embedding gradient first.  Its bucket is the largest of the step (256 I floats) and
         # its all-reduce then runs under the GRU weight-gradient kernels; the GRU bucket that ends the step is 1.3 MB.
-        self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
-        # embedding: dense gradient, zero + deterministic segmented scatter-add
-        ge = self.Gv("item_embed.weight")
-        if not prepped:
-            _lib.call("svae_zero", ge.data_ptr(), 4 * ge.numel(), st)
-        self._prepped_grad = False
-        _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
-                  plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, plan.nseg_long, 1.0, st)
-        self._bucket(3)
-        # (Tried: these two on a second side stream beside dL/demb -> scatter-add.  2.5 % SLOWER, 1.153 vs 1.123 ms
-        # per step: the tail of backward is short of bandwidth, not of parallelism.)
-        self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
-        self._wgrad(w["dgi"], w["emb"], "gru.weight_ih_l0", R, G, E, G, E)
-        self._bucket(2)
+        def embedding_grad():
+            self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
+            # embedding: dense gradient, zero + deterministic segmented scatter-add
+            ge = self.Gv("item_embed.weight")
+            if not prepped:
+                _lib.call("svae_zero", ge.data_ptr(), 4 * ge.numel(), st)
+            self._prepped_grad = False
+            _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
+                      plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, plan.nseg_long, 1.0, st)
+            self._bucket(2)
+
+        def gru_wgrads():
+            # (Tried: these two on a second side stream beside dL/demb -> scatter-add.  2.5 % SLOWER, 1.153 vs 1.123 ms
+            # per step: the tail of backward is short of bandwidth, not of parallelism.)
+            self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
+            self._wgrad(w["dgi"], w["emb"], "gru.weight_ih_l0", R, G, E, G, E)
+
+        if self.tail_embedding_first:
+            embedding_grad()
+            gru_wgrads()
+        else:
+            gru_wgrads()
+            embedding_grad()
         if side is not None:
             cur.wait_stream(side)
         elif self._loss_deferred:
             _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
         self._loss_deferred = False
+        self._bucket(1)      # dense layers (side stream) + GRU (this stream): behind the join
 
     # ------------------------------------------------------------------ dense (notebook) surface
     def dense_loss(self, logits, mu, ls, tgt, anneal, batch_size=1.0):

@@ -102,11 +102,14 @@ class ParamLayout:
             out[name] = v.reshape(self.ref_shapes[name]).clone()
         return out
 
-    def buckets(self, n_buckets=4):
-        """Contiguous [start, end) slices of the flat buffer for bucketed gradient all-reduce, in
-        backward-readiness order.  Bucket 0 = decoder.linear2.*, last bucket = item_embed."""
+    def buckets(self, n_buckets=3):
+        """Contiguous [start, end) slices of the flat buffer for bucketed gradient all-reduce.
+        Bucket 0 = decoder.linear2.* (151 I floats; ready when the weight-gradient sweep of the projection has
+        finished, on the side stream), bucket 1 = the small dense layers and the GRU (0.33 M floats; the last
+        gradients of the step), bucket 2 = item_embed (256 I floats; ready before the GRU weight gradients, see
+        engine.backward).  Three collectives per step: every one costs host time and a stream hand-over."""
         names = list(self.entries.keys())
-        groups = [names[0:2], names[2:8], names[8:12], names[12:13]]
+        groups = [names[0:2], names[2:12], names[12:13]]
         out = []
         for gnames in groups:
             s = self.entries[gnames[0]].offset
