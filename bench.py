@@ -87,6 +87,8 @@ def main():
         else:
             sd[name] = (torch.rand(shp) * 2 - 1) * 0.05
     eng.load_state_dict(sd)
+    for p_ in plans:
+        eng.prepare(p_)
     if world > 1 or rehearse:
         eng.grad_sync = GradSync(eng.grads, eng.layout.buckets(), force=rehearse)
 

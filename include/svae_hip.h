@@ -69,6 +69,10 @@ int svae_embed_bwd(const float* demb, const int* perm, const int* seg_off, const
  * dhs [R][224] in; dgi [R][672] = d/d gi, dgh [R][672] = d/d gh out. */
 int svae_gru_fwd(const float* gi, const float* whh, const float* bhh, const int* row_off, const int* nact, int B,
                  int Tmax, float* hs, float* hprev, float* gates4, int prec, void* stream);
+/* Timesteps [t0, t1) of the same recurrence; t0 > 0 continues from hs (bf16 kernel only).  No counterpart in the
+ * reference (one nn.GRU call, nb:759): the host runs the second range beside the decoder side of the first. */
+int svae_gru_fwd_range(const float* gi, const float* whh, const float* bhh, const int* row_off, const int* nact, int B,
+                       int Tmax, int t0, int t1, float* hs, float* hprev, float* gates4, int prec, void* stream);
 int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t, const int* row_off,
                  const int* nact, int B, int Tmax, float* dgi, float* dgh, int prec, void* stream);
 
@@ -134,6 +138,9 @@ int svae_proj_ns_max(void);
 int svae_proj_schedule(int nx, int ny, int ncu, int uniform, int* sched_host, int cap, int* ns_q, int* ns_rem);
 int svae_proj_tile(void);
 int svae_proj_prep_rows(const float* h2, int R, int R_pad, void* h2b, void* h2s, void* h2tb, void* stream);
+/* rows [row0, row1) only (multiples of 32; pointers of the whole arrays) */
+int svae_proj_prep_rows_range(const float* h2, int R, int R_pad, int row0, int row1, void* h2b, void* h2s, void* h2tb,
+                              void* stream);
 int svae_proj_prep_items(const float* w3, const float* b3, int I, int I_pad, void* w3b, void* w3s, void* w3tb,
                          void* stream);
 int svae_proj_nll_fwd(const void* h2s, const void* w3b, const float* h2, const float* w3, const float* b3,

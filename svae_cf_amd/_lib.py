@@ -23,6 +23,8 @@ SIGNATURES = {
     "svae_reduce_slabs": [_P, _P, _LL, _I, _LL, _P],
     "svae_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _LL, _P],
     "svae_gru_fwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
+    "svae_gru_fwd_range": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    "svae_proj_prep_rows_range": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
     "svae_gru_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "svae_embed_fwd": [_P, _P, _P, _I, _I, _P],
     "svae_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _F, _P],

@@ -69,6 +69,7 @@ struct GruArgs {
     float* dgi;           // [R][672]  (bwd out) d/d(gi) = (dr_pre, dz_pre, dn_pre)
     float* dgh;           // [R][672]  (bwd out) d/d(gh) = (dr_pre, dz_pre, dn_pre * r)
     int B, Tmax;
+    int t0, t1;           // forward, bf16 kernel: timesteps [t0, t1) of the recurrence (t0 > 0: h_{t0-1} is read from hs)
 };
 
 // forward gate math for one owned element; returns h_t
@@ -376,14 +377,32 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
     const __amdgpu_buffer_rsrc_t hs_b = __builtin_amdgcn_make_buffer_rsrc(a.hs, 0, R * (SV_HP * 4u), SV_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t hp_b = __builtin_amdgcn_make_buffer_rsrc(a.hprev, 0, R * (SV_HP * 4u), SV_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t g4_b = __builtin_amdgcn_make_buffer_rsrc(a.gates4, 0, R * (SV_HP * 16u), SV_BUF_FLAGS);
-    int na = nact_s[0];
-    int rbase = roff_s[0] + u0;
+    int na = nact_s[a.t0];
+    int rbase = roff_s[a.t0] + u0;
+    if (a.t0 > 0) {
+        // resumed recurrence (the forward is launched in two time ranges so that the decoder side of the first
+        // range's rows runs beside the second): h_{t0-1} of the owned elements comes back from hs (fp32, what the
+        // first launch kept in registers) and its bf16 copy goes into the image step t0 reads
+        const int nprev = nact_s[a.t0 - 1];
+        if (lk < MU && u0 + lk < nprev) {
+            const size_t row = (size_t)(roff_s[a.t0 - 1] + u0 + lk);
+            unsigned short* hinit = h_bf + (a.t0 & 1) * (MB * HLDB);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int j = 16 * (wave + 8 * q) + ln;
+                const float h = a.hs[row * SV_HP + j];
+                hreg[q] = h;
+                hinit[lk * HLDB + j] = sv_f2bf(h);
+            }
+        }
+        __syncthreads();
+    }
 #ifdef SV_GRU_TIMING
     unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ts_last = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-    for (int t = 0; t < a.Tmax; ++t) {
+    for (int t = a.t0; t < a.t1; ++t) {
         if (na <= u0) break;
         SV_TS(0)
         const unsigned short* hcur = h_bf + (t & 1) * (MB * HLDB);
@@ -684,12 +703,26 @@ static int check_gru(const GruArgs& a, bool bwd) {
 }
 
 // Reference interface replaced: nn.GRU forward inside Model.forward (nb:759).
+extern "C" int svae_gru_fwd_range(const float* gi, const float* whh, const float* bhh, const int* row_off,
+                                  const int* nact, int B, int Tmax, int t0, int t1, float* hs, float* hprev,
+                                  float* gates4, int prec, void* stream);
 extern "C" int svae_gru_fwd(const float* gi, const float* whh, const float* bhh, const int* row_off,
                             const int* nact, int B, int Tmax, float* hs, float* hprev, float* gates4, int prec,
                             void* stream) {
-    GruArgs a{gi, whh, bhh, row_off, nact, hs, hprev, gates4, nullptr, nullptr, nullptr, B, Tmax};
+    return svae_gru_fwd_range(gi, whh, bhh, row_off, nact, B, Tmax, 0, Tmax, hs, hprev, gates4, prec, stream);
+}
+
+// The same recurrence over timesteps [t0, t1) only.  t0 > 0 continues a recurrence whose steps < t0 have been
+// run (hs holds h_{t0-1}); bf16 kernel only.  No counterpart in the reference (one cuDNN call there): the split
+// lets the host overlap the second range with the decoder side of the first range's rows.
+extern "C" int svae_gru_fwd_range(const float* gi, const float* whh, const float* bhh, const int* row_off,
+                                  const int* nact, int B, int Tmax, int t0, int t1, float* hs, float* hprev,
+                                  float* gates4, int prec, void* stream) {
+    GruArgs a{gi, whh, bhh, row_off, nact, hs, hprev, gates4, nullptr, nullptr, nullptr, B, Tmax, t0, t1};
     if (int e = check_gru(a, false)) return e;
     SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gru_fwd: bad prec %d", prec);
+    SV_CHECK_ARG(t0 >= 0 && t0 < t1 && t1 <= Tmax, "svae_gru_fwd_range: bad range [%d, %d) of %d", t0, t1, Tmax);
+    SV_CHECK_ARG(prec == 1 || (t0 == 0 && t1 == Tmax), "svae_gru_fwd_range: the fp32 kernel runs whole sequences only");
     dim3 grid((B + MB - 1) / MB);
     if (prec == 0) {
         hipLaunchKernelGGL(gru_fwd_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -712,7 +745,7 @@ extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* g
                             const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dgh,
                             int prec, void* stream) {
     GruArgs a{nullptr, whh_t, nullptr, row_off, nact, nullptr, const_cast<float*>(hprev),
-              const_cast<float*>(gates4), dhs, dgi, dgh, B, Tmax};
+              const_cast<float*>(gates4), dhs, dgi, dgh, B, Tmax, 0, Tmax};
     if (int e = check_gru(a, true)) return e;
     SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gru_bwd: bad prec %d", prec);
     dim3 grid((B + MB - 1) / MB);

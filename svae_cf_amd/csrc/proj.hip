@@ -429,9 +429,9 @@ __device__ __forceinline__ int korder(int y) { return (y & ~12) | ((y & 4) << 1)
 template <int ROWS>
 __global__ void proj_prep_kernel(const float* __restrict__ src, const float* __restrict__ bias,
                                  unsigned short* __restrict__ dst, unsigned short* __restrict__ dsts,
-                                 unsigned short* __restrict__ dstT, int n, int n_pad, int ldt) {
+                                 unsigned short* __restrict__ dstT, int n, int n_pad, int ldt, int row0) {
     __shared__ unsigned short tile[32][KP + 2];
-    const int r0 = blockIdx.x * 32;
+    const int r0 = row0 + blockIdx.x * 32;
     const unsigned short one = 0x3F80;
     for (int i = threadIdx.x; i < 32 * KP; i += blockDim.x) {
         const int r = i / KP, c = i % KP;
@@ -798,11 +798,22 @@ extern "C" int svae_proj_occ_long(void) { return OCC_LONG; }
 
 // bf16 operand copies of the decoder hidden rows (fp32 h2 [R][160], the tanh output of Decoder.linear1 nb:709):
 // h2b [R_pad][160] plain, h2s [R_pad][160] scaled by log2(e), h2tb [160][R_pad] transposed; R_pad % 64 == 0.
+extern "C" int svae_proj_prep_rows_range(const float* h2, int R, int R_pad, int row0, int row1, void* h2b, void* h2s,
+                                         void* h2tb, void* stream);
 extern "C" int svae_proj_prep_rows(const float* h2, int R, int R_pad, void* h2b, void* h2s, void* h2tb,
                                    void* stream) {
+    return svae_proj_prep_rows_range(h2, R, R_pad, 0, R_pad, h2b, h2s, h2tb, stream);
+}
+
+// The same for rows [row0, row1) only (multiples of 32; all pointers are those of the whole arrays).
+extern "C" int svae_proj_prep_rows_range(const float* h2, int R, int R_pad, int row0, int row1, void* h2b, void* h2s,
+                                         void* h2tb, void* stream) {
     SV_CHECK_ARG(h2 && h2b && h2s && h2tb && R > 0 && R_pad >= R && (R_pad % BY) == 0, "svae_proj_prep_rows: bad arguments");
-    hipLaunchKernelGGL(proj_prep_kernel<1>, dim3(R_pad / 32), dim3(256), 0, (hipStream_t)stream, h2, (const float*)nullptr,
-                       (unsigned short*)h2b, (unsigned short*)h2s, (unsigned short*)h2tb, R, R_pad, R_pad);
+    SV_CHECK_ARG(row0 >= 0 && row0 < row1 && row1 <= R_pad && (row0 % 32) == 0 && (row1 % 32) == 0,
+                 "svae_proj_prep_rows_range: bad range [%d, %d) of %d", row0, row1, R_pad);
+    hipLaunchKernelGGL(proj_prep_kernel<1>, dim3((row1 - row0) / 32), dim3(256), 0, (hipStream_t)stream, h2,
+                       (const float*)nullptr, (unsigned short*)h2b, (unsigned short*)h2s, (unsigned short*)h2tb, R, R_pad,
+                       R_pad, row0);
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -813,7 +824,7 @@ extern "C" int svae_proj_prep_items(const float* w3, const float* b3, int I, int
                                     void* w3tb, void* stream) {
     SV_CHECK_ARG(w3 && b3 && w3b && w3s && w3tb && I > 0 && I_pad >= I && (I_pad % BY) == 0, "svae_proj_prep_items: bad arguments");
     hipLaunchKernelGGL(proj_prep_kernel<0>, dim3(I_pad / 32), dim3(256), 0, (hipStream_t)stream, w3, b3,
-                       (unsigned short*)w3b, (unsigned short*)w3s, (unsigned short*)w3tb, I, I_pad, I_pad);
+                       (unsigned short*)w3b, (unsigned short*)w3s, (unsigned short*)w3tb, I, I_pad, I_pad, 0);
     SV_LAUNCH_CHECK();
     return 0;
 }

@@ -104,6 +104,7 @@ class SVAEEngine:
         self._prepped_grad = False
         self._dtmp_extra = None
         self._loss_deferred = False
+        self.time_split = os.environ.get("SVAE_TIME_SPLIT", "1") == "1"
         self.tail_embedding_first = os.environ.get("SVAE_TAIL", "emb") == "emb"
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.event_pool = []
@@ -315,11 +316,31 @@ class SVAEEngine:
                   w["emb"].data_ptr(), R, self.I, st)
         self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
                    bias=self.P("gru.bias_ih_l0"))
-        ev = self._tic("gru_fwd")
-        _lib.call("svae_gru_fwd", w["gi"].data_ptr(), self.P("gru.weight_hh_l0").data_ptr(),
-                  self.P("gru.bias_hh_l0").data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(),
-                  plan.B, plan.Tmax, w["hs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(), self.gru_prec, st)
-        self._toc("gru_fwd", ev)
+        # Two time ranges (batch.choose_time_split): the recurrence of steps >= t1 runs on the side stream beside
+        # the decoder side of the rows of steps < t1 (rows are time-major: the first r1 of them).
+        t1, r1 = (plan.split_t, plan.split_r) if (self.time_split and params_ready is not None and want_loss
+                                                  and want_grad and self.gru_prec == PREC_BF16) else (0, 0)
+
+        def gru_range(a, b, tag):
+            ev = self._tic(tag)
+            _lib.call("svae_gru_fwd_range", w["gi"].data_ptr(), self.P("gru.weight_hh_l0").data_ptr(),
+                      self.P("gru.bias_hh_l0").data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(),
+                      plan.B, plan.Tmax, a, b, w["hs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
+                      self.gru_prec, _stream())
+            self._toc(tag, ev)
+
+        second_done = None
+        if t1 > 0:
+            gru_range(0, t1, "gru_fwd")
+            first_done = torch.cuda.Event()
+            first_done.record(cur)
+            side.wait_event(first_done)
+            with _Launch(side, self._torch_ctx()):
+                gru_range(t1, plan.Tmax, "gru_fwd2")
+                second_done = torch.cuda.Event()
+                second_done.record(side)
+        else:
+            gru_range(0, plan.Tmax, "gru_fwd")
         if eps is not None:
             if eps.numel() != R * L:
                 raise ValueError("eps must have %d x %d elements" % (R, L))
@@ -333,12 +354,19 @@ class SVAEEngine:
                 cur.wait_event(params_ready)
             else:
                 self._param_prep(want_grad)
-            ev = self._tic("mlp_fwd")
-            _lib.call("svae_mlp_fwd", w["hs"].data_ptr(), w["eps"].data_ptr(), self.mlp_frags.data_ptr(),
-                      self.P("encoder.linear1.bias").data_ptr(), self.P("linear1.bias").data_ptr(),
-                      self.P("decoder.linear1.bias").data_ptr(), w["enc"].data_ptr(), w["tmp"].data_ptr(),
-                      w["z"].data_ptr(), w["d1"].data_ptr(), w["kl_row"].data_ptr(), R, st)
-            self._toc("mlp_fwd", ev)
+            if t1 > 0:
+                self._last_fused = True
+                self._decoder_rows(plan, 0, r1, self._ncu - (plan.B + 3) // 4)
+                cur.wait_event(second_done)
+                self._decoder_rows(plan, r1, R, self._ncu)
+                self._fused_grad = True
+                if defer_loss and self.overlap:
+                    self._loss_deferred = True
+                else:
+                    _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
+                              plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
+                return self.loss_out
+            self._mlp_fwd_rows(0, R)
         else:
             self._gemm(w["hs"], self.P("encoder.linear1.weight"), w["enc"], R, DP, HP, HP, HP, DP, 0, 0,
                        bias=self.P("encoder.linear1.bias"), act=1)
@@ -389,6 +417,35 @@ class SVAEEngine:
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
         return self.loss_out
 
+    def _mlp_fwd_rows(self, r0, r1):
+        w, n = self.ws, r1 - r0
+        ev = self._tic("mlp_fwd")
+        _lib.call("svae_mlp_fwd", w["hs"].data_ptr() + 4 * HP * r0, w["eps"].data_ptr() + 4 * L * r0,
+                  self.mlp_frags.data_ptr(), self.P("encoder.linear1.bias").data_ptr(),
+                  self.P("linear1.bias").data_ptr(), self.P("decoder.linear1.bias").data_ptr(),
+                  w["enc"].data_ptr() + 4 * DP * r0, w["tmp"].data_ptr() + 8 * L * r0, w["z"].data_ptr() + 4 * L * r0,
+                  w["d1"].data_ptr() + 4 * DP * r0, w["kl_row"].data_ptr() + 4 * r0, n, _stream())
+        self._toc("mlp_fwd", ev)
+
+    def _decoder_rows(self, plan, r0, r1, ncu):
+        """Decoder side of rows [r0, r1) of the plan (r0 a multiple of 64): MLP chain, bf16 operand copies, forward
+        + dL/dh sweep of the projection and its finish.  Every array is row-major, so a row range is a pointer
+        offset; the slab scratch of a range starts where the previous range's ends."""
+        w, R, n = self.ws, plan.R, r1 - r0
+        self._mlp_fwd_rows(r0, r1)
+        Rp = (R + 63) // 64 * 64
+        _lib.call("svae_proj_prep_rows_range", w["d1"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
+                  w["h2b"].data_ptr(), w["h2s"].data_ptr(), w["h2tb"].data_ptr(), _stream())
+        nsm = _lib.load().svae_proj_ns_max()
+        args = (w["h2s"].data_ptr() + 2 * DP * r0, w["h2b"].data_ptr() + 2 * DP * r0, self.w3b.data_ptr(),
+                self.w3tb.data_ptr(), self.IPAD, w["d1"].data_ptr() + 4 * DP * r0,
+                self.P("decoder.linear2.weight").data_ptr(), self.P("decoder.linear2.bias").data_ptr(),
+                plan.tgt.data_ptr() + 4 * plan.K * r0, plan.w_nll.data_ptr() + 4 * r0, n, self.I, plan.K,
+                w["pslabs"].data_ptr() + 4 * nsm * DP * r0, w["mpart"].data_ptr() + 4 * nsm * r0,
+                w["nll_row"].data_ptr() + 4 * r0, w["lse"].data_ptr() + 4 * r0,
+                w["dd1"].data_ptr() + 4 * DP * r0) + self._proj_sched(plan, "rows", nx=n, ncu=ncu)
+        self._split_call("svae_proj_nll_fwd_dh", args, ((1, "proj_fdh_fused"), (2, "proj_fdh_finish")))
+
     def _split_call(self, name, args, parts):
         """One C-ABI call covering several kernels; when profiling, one call per kernel so each is bracketed."""
         if self.prof is None:
@@ -399,21 +456,36 @@ class SVAEEngine:
             _lib.call(name, *args, bit, _stream())
             self._toc(tag, ev)
 
-    def _proj_sched(self, plan, side):
+    def _proj_sched(self, plan, side, nx=None, ncu=None):
         """(device table, nwg, ns_q, ns_rem) of a projection sweep over this plan: 'rows' = rows resident, items
-        streamed (forward / dL/dh sweep), 'items' = the weight-gradient sweep.  Built once per plan and engine."""
-        key = (side, self.I, self._ncu)
+        streamed (forward / dL/dh sweep; nx = the number of rows when only a range of the plan is swept), 'items' =
+        the weight-gradient sweep.  Built once per plan and engine."""
+        ncu = self._ncu if ncu is None else max(8, int(ncu))
+        key = (side, self.I, ncu, nx)
         cache = plan.proj_sched
         if key not in cache:
-            nx, ny = (plan.R, self.I) if side == "rows" else (self.I, plan.R)
-            uni = 0
-            if side == "items":
+            if side == "rows":
+                tab, q, rem = _lib.proj_schedule(plan.R if nx is None else nx, self.I, ncu, uniform=0)
+            else:
                 fq = int(os.environ.get("SVAE_DW_Q", "0"))
-                uni = 1 + fq if fq > 0 else 1
-            tab, q, rem = _lib.proj_schedule(nx, ny, int(os.environ.get("SVAE_DW_CUS", self._ncu)) if uni else self._ncu, uniform=uni)
+                tab, q, rem = _lib.proj_schedule(self.I, plan.R, ncu, uniform=1 + fq if fq > 0 else 1)
             cache[key] = (torch.from_numpy(tab).to(self.device), int(tab.shape[0]), q, rem)
         t, n, q, rem = cache[key]
         return (t.data_ptr(), n, q, rem)
+
+    def prepare(self, plan):
+        """Build and upload everything the fused step derives from a plan (the work division tables of the
+        projection sweeps) BEFORE the step is launched.  Built lazily instead, the upload is a synchronous copy on
+        the caller's stream in the middle of backward: the host waits for the GRU's BPTT and the weight-gradient
+        sweep starts after it rather than beside it (seen in a kernel trace: +0.2-0.4 ms on a plan's first step)."""
+        if not self.fused:
+            return plan
+        self._proj_sched(plan, "rows")
+        self._proj_sched(plan, "items")
+        if self.time_split and plan.split_t > 0:
+            self._proj_sched(plan, "rows", nx=plan.split_r, ncu=self._ncu - (plan.B + 3) // 4)
+            self._proj_sched(plan, "rows", nx=plan.R - plan.split_r, ncu=self._ncu)
+        return plan
 
     def _param_prep(self, want_grad):
         """Per-step work that depends on the parameters only (they change at every optimizer step)."""

@@ -362,6 +362,7 @@ def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, 
     for b, idx in enumerate(batches, start=1):
         plan = build_plan([np.asarray(reader.data[i]) for i in idx], k, user_keys=idx, device=eng.device,
                           total_items=eng.I)
+        eng.prepare(plan)
         eng.train_step(plan, anneal_for_batch(b), seed=seed + epoch)
         if log is not None and b % max(1, hyper_params["batch_log_interval"] // batch_size) == 0:
             log("| epoch {:3d} | {:5d}/{:5d} batches | loss {:5.4f}".format(epoch, b, len(batches), float(eng.loss_out[0])))

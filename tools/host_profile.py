@@ -11,6 +11,8 @@ rng = np.random.default_rng(98765)
 batches = synth.bucketed_batches([len(u) for u in users], B, rng)
 plans = [S.build_plan([users[i] for i in idx], 4, user_keys=idx, device="cuda", total_items=I) for idx in batches]
 eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+for p_ in plans:
+    eng.prepare(p_)
 for i in range(8):
     eng.train_step(plans[i % 8], 0.01, seed=1)
 torch.cuda.synchronize()

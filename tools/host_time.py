@@ -11,6 +11,8 @@ rng = np.random.default_rng(98765)
 batches = synth.bucketed_batches([len(u) for u in users], B, rng)
 plans = [S.build_plan([users[i] for i in idx], 4, user_keys=idx, device="cuda", total_items=I) for idx in batches]
 eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+for p_ in plans:
+    eng.prepare(p_)
 if "--rccl" in sys.argv:      # world-size-1 process group on RCCL, all-reduces kept (needs MASTER_ADDR/PORT, RANK, WORLD_SIZE)
     import torch.distributed as dist
     from svae_cf_amd.dist import GradSync
