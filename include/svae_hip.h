@@ -50,6 +50,15 @@ int svae_reduce_slabs(const float* slabs, float* out, long long n, int nsplit, l
 int svae_wgrad(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy, int ldx,
                int nsplit, long long slab_stride, void* stream);
 
+/* Row-panel form of the two GRU-side contractions (bf16 MFMA path; csrc/rowgemm.hip), replacing the same call
+ * sites as svae_gemm does for them: which 0: gi [R][672] = emb [R][256] W_ih^T + b_ih (input GEMM of nn.GRU,
+ * nb:759); which 1: demb [R][256] = dgi [R][672] W_ih (its data gradient, nb:1205).  svae_rowgemm_prep lays
+ * W_ih ([672][256] fp32 as stored) out as bf16 fragments (svae_rowgemm_frag_elems(which) elements) whenever it
+ * has changed. */
+int svae_rowgemm_frag_elems(int which);
+int svae_rowgemm_prep(const float* wih, int which, void* frags, void* stream);
+int svae_rowgemm(const float* x, const void* frags, const float* bias, float* y, int R, int which, void* stream);
+
 /* ---- item embedding ----------------------------------------------------------------------------
  * svae_embed_fwd replaces self.item_embed(x) nb:756: out[r][:] = table[x[r]][:] (E = 256).
  * svae_embed_bwd replaces the embedding backward of loss.backward() nb:1205 as a deterministic

@@ -52,6 +52,9 @@ SIGNATURES = {
     "svae_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "svae_mlp_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "svae_spin": [_I, _P],
+    "svae_rowgemm_frag_elems": [_I],
+    "svae_rowgemm_prep": [_P, _I, _P, _P],
+    "svae_rowgemm": [_P, _P, _P, _P, _I, _I, _P],
     "svae_zero": [_P, _LL, _P],
     "svae_proj_nsplit": [],
     "svae_proj_tile": [],

@@ -105,6 +105,7 @@ class SVAEEngine:
         self._dtmp_extra = None
         self._loss_deferred = False
         self.time_split = os.environ.get("SVAE_TIME_SPLIT", "1") == "1"
+        self.rowgemm = os.environ.get("SVAE_ROWGEMM", "1") == "1"
         self.tail_embedding_first = os.environ.get("SVAE_TAIL", "emb") == "emb"
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.event_pool = []
@@ -167,6 +168,7 @@ class SVAEEngine:
             self.ws["pslabs"] = torch.empty(nsm * capp * DP, **f32)
             self.ws["pslabs_side"] = torch.empty(nsm * self.IPAD * DP, **f32)
             if self.w3b is None:
+                self.wih_frags = [torch.zeros(_lib.load().svae_rowgemm_frag_elems(i), **bf) for i in (0, 1)]
                 self.mlp_frags = torch.zeros(_lib.load().svae_mlp_frag_elems(), **bf)
                 self.w3b = torch.zeros(self.IPAD * DP, **bf)
                 self.w3s = torch.zeros(self.IPAD * DP, **bf)
@@ -314,8 +316,17 @@ class SVAEEngine:
                 params_ready.record(side)
         _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
                   w["emb"].data_ptr(), R, self.I, st)
-        self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
-                   bias=self.P("gru.bias_ih_l0"))
+        if self.fused and self.rowgemm:
+            # W_ih fragments are built here, on the caller's stream (the GEMM is the second kernel of the step: the
+            # side stream's preparation would not be ready in time), 2 us
+            _lib.call("svae_rowgemm_prep", self.P("gru.weight_ih_l0").data_ptr(), 0, self.wih_frags[0].data_ptr(), st)
+            ev = self._tic("gi_gemm")
+            _lib.call("svae_rowgemm", w["emb"].data_ptr(), self.wih_frags[0].data_ptr(),
+                      self.P("gru.bias_ih_l0").data_ptr(), w["gi"].data_ptr(), R, 0, st)
+            self._toc("gi_gemm", ev)
+        else:
+            self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
+                       bias=self.P("gru.bias_ih_l0"))
         # Two time ranges (batch.choose_time_split): the recurrence of steps >= t1 runs on the side stream beside
         # the decoder side of the rows of steps < t1 (rows are time-major: the first r1 of them).
         t1, r1 = (plan.split_t, plan.split_r) if (self.time_split and params_ready is not None and want_loss
@@ -495,6 +506,8 @@ class SVAEEngine:
         _lib.call("svae_proj_prep_items", self.P("decoder.linear2.weight").data_ptr(),
                   self.P("decoder.linear2.bias").data_ptr(), self.I, self.IPAD, self.w3b.data_ptr(),
                   self.w3s.data_ptr(), self.w3tb.data_ptr(), st)
+        if want_grad and self.rowgemm:
+            _lib.call("svae_rowgemm_prep", self.P("gru.weight_ih_l0").data_ptr(), 1, self.wih_frags[1].data_ptr(), st)
         if want_grad:
             _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
             e = self.layout.entries["item_embed.weight"]
@@ -625,7 +638,13 @@ class SVAEEngine:
         # Order of the tail: the embedding gradient first.  Its bucket is the largest of the step (256 I floats) and
         # its all-reduce then runs under the GRU weight-gradient kernels; the GRU bucket that ends the step is 1.3 MB.
         def embedding_grad():
-            self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
+            if self.fused and self.rowgemm and prepped:
+                ev = self._tic("demb_gemm")
+                _lib.call("svae_rowgemm", w["dgi"].data_ptr(), self.wih_frags[1].data_ptr(), None, w["demb"].data_ptr(),
+                          R, 1, st)
+                self._toc("demb_gemm", ev)
+            else:
+                self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
             # embedding: dense gradient, zero + deterministic segmented scatter-add
             ge = self.Gv("item_embed.weight")
             if not prepped:

@@ -238,3 +238,29 @@ def test_bf16_mode_larger_batch_vs_oracle():
     eng.backward()
     torch.cuda.synchronize()
     assert torch.equal(g1, eng.grads)
+
+
+@pytest.mark.parametrize("R", [1, 127, 1000, 4097])
+def test_rowgemm_matches_fp32_product_of_bf16_operands(R):
+    """Row-panel GEMM of the GRU input side (csrc/rowgemm.hip) against torch on the same bf16-rounded operands:
+    gi = emb W_ih^T + b (which 0) and demb = dgi W_ih (which 1).  The kernel accumulates exact bf16 x bf16
+    products in fp32, so only the summation order differs: 2e-5 of the result's scale (K <= 672 terms)."""
+    from svae_cf_amd import _lib
+    from svae_cf_amd.layout import E, G
+    g = torch.Generator().manual_seed(R)
+    wih = (torch.randn(G, E, generator=g) * 0.1).cuda()
+    bias = torch.randn(G, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    wb = wih.bfloat16().float()
+    for which, (K, N) in enumerate(((E, G), (G, E))):
+        x = torch.randn(R, K, generator=g).cuda()
+        frags = torch.zeros(_lib.load().svae_rowgemm_frag_elems(which), dtype=torch.bfloat16, device="cuda")
+        y = torch.full((R, N), float("nan"), device="cuda")
+        _lib.call("svae_rowgemm_prep", wih.data_ptr(), which, frags.data_ptr(), st)
+        _lib.call("svae_rowgemm", x.data_ptr(), frags.data_ptr(), bias.data_ptr() if which == 0 else None,
+                  y.data_ptr(), R, which, st)
+        torch.cuda.synchronize()
+        xb = x.bfloat16().float()
+        ref = xb @ wb.t() + bias if which == 0 else xb @ wb
+        err = float((y - ref).abs().max())
+        assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, (which, R, err)
