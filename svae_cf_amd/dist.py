@@ -37,17 +37,22 @@ class GradSync:
             return
         s, e = self.buckets[i]
         if self.device_collectives or not self.flat.is_cuda:
-            self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                async_op=True))
+            self.pending.append((i, dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True)))
             return
         host = self.flat[s:e].to("cpu")            # ordered behind the current stream, blocks until copied
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
         self.flat[s:e].copy_(host)                 # on the current stream as well
 
-    def wait(self):
-        for w in self.pending:
-            w.wait()
-        self.pending = []
+    def wait(self, which=None):
+        """Order the current stream behind the all-reduces of the buckets in `which` (None: all of them)."""
+        keep = []
+        for i, w in self.pending:
+            if which is None or i in which:
+                w.wait()
+            else:
+                keep.append((i, w))
+        self.pending = keep
 
     @property
     def gscale(self):

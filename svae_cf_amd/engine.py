@@ -106,6 +106,16 @@ class SVAEEngine:
         self._loss_deferred = False
         self.time_split = os.environ.get("SVAE_TIME_SPLIT", "1") == "1"
         self.rowgemm = os.environ.get("SVAE_ROWGEMM", "1") == "1"
+        # train_step only: the decoder.linear2 gradient work (weight-gradient sweep, its finish, the bucket's
+        # all-reduce, Adam over the bucket, the bf16 operand copies of the new weights) runs on a stream of its own
+        # and the step does not wait for it -- it finishes under the next step's embedding / input GEMM / first
+        # recurrence range, which leave most of the GPU idle, and the next step waits for it before its decoder side
+        self.float_w3 = os.environ.get("SVAE_FLOAT_W3", "1") == "1"
+        self._in_step = False
+        self._float_pending = False
+        self._float_plan = None
+        self._w3_event = None          # recorded on the w3 stream behind the floated work of the last train_step
+        self._w3_fresh = False         # w3b / w3s / w3tb match the current parameters (made by the floated work)
         self.tail_embedding_first = os.environ.get("SVAE_TAIL", "emb") == "emb"
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.event_pool = []
@@ -129,16 +139,28 @@ class SVAEEngine:
         them; otherwise the raw launch pointer is enough (and much cheaper)."""
         return self.grad_sync is not None
 
+    def _settle(self):
+        """Order the caller's stream behind work a train_step left floating on the w3 stream."""
+        if self._w3_event is not None:
+            torch.cuda.current_stream().wait_event(self._w3_event)
+            self._w3_event = None
+            self._float_plan = None
+
     def load_state_dict(self, sd):
+        self._settle()
+        self._w3_fresh = False
         self.layout.pack(sd, self.params)
 
     def state_dict(self):
+        self._settle()
         return self.layout.unpack(self.params)
 
     def grad_dict(self):
+        self._settle()
         return self.layout.unpack(self.grads)
 
     def reset_optimizer(self):
+        self._settle()
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         self.step_count = 0
@@ -147,6 +169,9 @@ class SVAEEngine:
     def _ensure(self, R):
         if R <= self.cap:
             return
+        if self._w3_event is not None:     # floated kernels still read the workspace that is about to be replaced
+            self._settle()
+            torch.cuda.current_stream().synchronize()
         cap = int(R * 1.25) + 64
         f32 = dict(device=self.device, dtype=torch.float32)
         shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dgh=G, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
@@ -290,6 +315,8 @@ class SVAEEngine:
         np.random.normal draws, nb:744); otherwise Philox noise keyed by (seed, step, row_key).
         After the call ``ws['logits']`` holds the logits (want_grad=False) or dlogits (want_grad=True).
         """
+        if not self._in_step:
+            self._settle()
         cur = torch.cuda.current_stream()
         with _Launch(cur):
             return self._forward(cur, plan, anneal, eps, seed, step, want_grad, want_loss, defer_loss)
@@ -302,18 +329,11 @@ class SVAEEngine:
         params_ready = None
         eps_done = False
         if self.fused and self.overlap:
-            # everything that depends on the parameters only (bf16 operand copies, weight fragments, W_hh^T, the
-            # zero fill of the embedding gradient) runs on the side stream beside the embedding / GRU kernels
             side = self._side_stream(cur=cur)
-            side.wait_stream(cur)
-            with _Launch(side, self._torch_ctx()):
-                self._param_prep(want_grad)
-                if eps is None:               # the noise depends on the plan and the step only
-                    _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
-                              int(step) & 0xFFFFFFFF, _stream())
-                    eps_done = True
-                params_ready = torch.cuda.Event()
-                params_ready.record(side)
+            step_begin = torch.cuda.Event()
+            step_begin.record(cur)
+        # the caller's stream first: its kernels head the critical path, the side stream's are not needed before the
+        # decoder side
         _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
                   w["emb"].data_ptr(), R, self.I, st)
         if self.fused and self.rowgemm:
@@ -327,6 +347,18 @@ class SVAEEngine:
         else:
             self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
                        bias=self.P("gru.bias_ih_l0"))
+        if self.fused and self.overlap:
+            # everything that depends on the parameters only (bf16 operand copies, weight fragments, W_hh^T, the
+            # zero fill of the embedding gradient) runs on the side stream beside the embedding / GRU kernels
+            side.wait_event(step_begin)
+            with _Launch(side, self._torch_ctx()):
+                self._param_prep(want_grad)
+                if eps is None:               # the noise depends on the plan and the step only
+                    _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
+                              int(step) & 0xFFFFFFFF, _stream())
+                    eps_done = True
+                params_ready = torch.cuda.Event()
+                params_ready.record(side)
         # Two time ranges (batch.choose_time_split): the recurrence of steps >= t1 runs on the side stream beside
         # the decoder side of the rows of steps < t1 (rows are time-major: the first r1 of them).
         t1, r1 = (plan.split_t, plan.split_r) if (self.time_split and params_ready is not None and want_loss
@@ -365,6 +397,12 @@ class SVAEEngine:
                 cur.wait_event(params_ready)
             else:
                 self._param_prep(want_grad)
+            if self._w3_event is not None:
+                # the last step's floated decoder.linear2 work: it read d1 / h2b / h2tb, which the kernels below
+                # overwrite, and it made the operand copies of the new weights, which they read
+                cur.wait_event(self._w3_event)
+                self._w3_event = None
+                self._float_plan = None       # (kept alive until here: the floated kernels read its tables)
             if t1 > 0:
                 self._last_fused = True
                 self._decoder_rows(plan, 0, r1, self._ncu - (plan.B + 3) // 4)
@@ -503,9 +541,8 @@ class SVAEEngine:
         st = _stream()
         _lib.call("svae_mlp_prep", self.P("encoder.linear1.weight").data_ptr(), self.P("linear1.weight").data_ptr(),
                   self.P("decoder.linear1.weight").data_ptr(), self.mlp_frags.data_ptr(), st)
-        _lib.call("svae_proj_prep_items", self.P("decoder.linear2.weight").data_ptr(),
-                  self.P("decoder.linear2.bias").data_ptr(), self.I, self.IPAD, self.w3b.data_ptr(),
-                  self.w3s.data_ptr(), self.w3tb.data_ptr(), st)
+        if not self._w3_fresh:
+            self._proj_prep_items(st)
         if want_grad and self.rowgemm:
             _lib.call("svae_rowgemm_prep", self.P("gru.weight_ih_l0").data_ptr(), 1, self.wih_frags[1].data_ptr(), st)
         if want_grad:
@@ -513,6 +550,11 @@ class SVAEEngine:
             e = self.layout.entries["item_embed.weight"]
             _lib.call("svae_zero", self._gbase + 4 * e.offset, 4 * e.size, st)
         self._prepped_grad = bool(want_grad)
+
+    def _proj_prep_items(self, st):
+        _lib.call("svae_proj_prep_items", self.P("decoder.linear2.weight").data_ptr(),
+                  self.P("decoder.linear2.bias").data_ptr(), self.I, self.IPAD, self.w3b.data_ptr(),
+                  self.w3s.data_ptr(), self.w3tb.data_ptr(), st)
 
     def _proj_prepare(self, R):
         """bf16 operand copies of the decoder hidden rows for the fused projection kernels."""
@@ -524,6 +566,7 @@ class SVAEEngine:
     def dense_logits(self, rows_idx=None):
         """Dense logits [n, I] for all rows of the last forward (rows_idx None) or a gathered subset
         (int32 device tensor).  This is the Model.forward / evaluate() surface; training never calls it."""
+        self._settle()
         plan, st = self._plan, _stream()
         f32 = dict(device=self.device, dtype=torch.float32)
         if rows_idx is None:
@@ -550,6 +593,8 @@ class SVAEEngine:
         """Gradients of the batched loss w.r.t. every parameter into ``self.grads``.
 
         Expects ``forward(..., want_grad=True)`` before it (ws['logits'] holds dlogits)."""
+        if not self._in_step:
+            self._settle()
         cur = torch.cuda.current_stream()
         with _Launch(cur):
             self._backward(cur)
@@ -627,13 +672,22 @@ class SVAEEngine:
             # gated on the chain above, enqueued after the recurrence so that its few workgroups get their CUs
             # first; the weight-gradient kernels then take whatever the recurrence leaves idle
             side.wait_event(chain_done)
+            floating = self._in_step and self.float_w3 and self._last_fused
+            if floating:
+                w3 = self._side_stream(1, cur=cur)
+                w3.wait_event(chain_done)
+                with _Launch(w3, self._torch_ctx()):
+                    proj_dw(w["pslabs_side"])
+                    self._bucket(0)
+                self._float_pending = True
             with _Launch(side, self._torch_ctx()):
                 if self._loss_deferred:
                     _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(),
                               plan.w_nll.data_ptr(), plan.w_kl.data_ptr(), float(anneal), R,
                               self.loss_out.data_ptr(), _stream())
-                proj_dw(w["pslabs_side"])
-                self._bucket(0)
+                if not floating:
+                    proj_dw(w["pslabs_side"])
+                    self._bucket(0)
                 decoder_side_wgrads(self.slabs_side)
         # Order of the tail: the embedding gradient first.  Its bucket is the largest of the step (256 I floats) and
         # its all-reduce then runs under the GRU weight-gradient kernels; the GRU bucket that ends the step is 1.3 MB.
@@ -720,21 +774,51 @@ class SVAEEngine:
 
     # ------------------------------------------------------------------ optimizer
     def adam_step(self, gscale=1.0):
+        self._settle()
+        self._w3_fresh = False
         self.step_count += 1
-        _lib.call("svae_adam_step", self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
-                  self.exp_avg_sq.data_ptr(), self.layout.total, self.step_count, self.lr, self.betas[0],
-                  self.betas[1], self.adam_eps, self.weight_decay, float(gscale), _stream())
+        self._adam_range(0, self.layout.total, gscale, _stream())
+
+    def _adam_range(self, s, e, gscale, st):
+        _lib.call("svae_adam_step", self.params.data_ptr() + 4 * s, self.grads.data_ptr() + 4 * s,
+                  self.exp_avg.data_ptr() + 4 * s, self.exp_avg_sq.data_ptr() + 4 * s, e - s, self.step_count, self.lr,
+                  self.betas[0], self.betas[1], self.adam_eps, self.weight_decay, float(gscale), st)
 
     def train_step(self, plan, anneal, eps=None, seed=0, step=None):
         """forward + backward + Adam for one batch.  Returns the device tensor holding
         [loss, likelihood, KL]; reading it synchronises, so do that only when logging."""
-        self.forward(plan, anneal, eps=eps, seed=seed, step=self.step_count if step is None else step, defer_loss=True)
-        self.backward()
-        if self.grad_sync is not None:
-            self.grad_sync.wait()
-            self.adam_step(self.grad_sync.gscale)
-        else:
-            self.adam_step()
+        self._in_step = True
+        try:
+            self.forward(plan, anneal, eps=eps, seed=seed, step=self.step_count if step is None else step,
+                         defer_loss=True)
+            self.backward()
+        finally:
+            self._in_step = False
+        gs = self.grad_sync
+        gscale = gs.gscale if gs is not None else 1.0
+        if not self._float_pending:
+            if gs is not None:
+                gs.wait()
+            self.adam_step(gscale)
+            return self.loss_out
+        # floated decoder.linear2 bucket: Adam over the other buckets here, over that one on its own stream
+        self._float_pending = False
+        self.step_count += 1
+        (s0, e0), rest = self.layout.buckets()[0], self.layout.buckets()[1:]
+        cur = torch.cuda.current_stream()
+        if gs is not None:
+            gs.wait(which=[i for i in range(1, 1 + len(rest))])
+        self._adam_range(rest[0][0], rest[-1][1], gscale, cur.cuda_stream)
+        w3 = self._side_stream(1, cur=cur)
+        with _Launch(w3, gs is not None):
+            if gs is not None:
+                gs.wait(which=[0])
+            self._adam_range(s0, e0, gscale, _stream())
+            self._proj_prep_items(_stream())
+        self._w3_event = torch.cuda.Event()
+        self._w3_event.record(w3)
+        self._w3_fresh = True
+        self._float_plan = plan
         return self.loss_out
 
     # ------------------------------------------------------------------ scoring
