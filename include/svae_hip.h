@@ -49,6 +49,9 @@ int svae_reduce_slabs(const float* slabs, float* out, long long n, int nsplit, l
  * See csrc/wgrad.hip. */
 int svae_wgrad(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy, int ldx,
                int nsplit, long long slab_stride, void* stream);
+/* dy's logical column n is stored column n + (n >= remap_from ? remap_add : 0) */
+int svae_wgrad_cols(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy, int ldx,
+                    int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream);
 
 /* Row-panel form of the two GRU-side contractions (bf16 MFMA path; csrc/rowgemm.hip), replacing the same call
  * sites as svae_gemm does for them: which 0: gi [R][672] = emb [R][256] W_ih^T + b_ih (input GEMM of nn.GRU,
@@ -58,6 +61,8 @@ int svae_wgrad(const float* dy, const float* x, float* out, float* colsum, int R
 int svae_rowgemm_frag_elems(int which);
 int svae_rowgemm_prep(const float* wih, int which, void* frags, void* stream);
 int svae_rowgemm(const float* x, const void* frags, const float* bias, float* y, int R, int which, void* stream);
+int svae_rowgemm_ld(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,
+                    void* stream);   /* rows of x ldx floats apart */
 
 /* ---- item embedding ----------------------------------------------------------------------------
  * svae_embed_fwd replaces self.item_embed(x) nb:756: out[r][:] = table[x[r]][:] (E = 256).
@@ -82,6 +87,8 @@ int svae_gru_fwd(const float* gi, const float* whh, const float* bhh, const int*
  * reference (one nn.GRU call, nb:759): the host runs the second range beside the decoder side of the first. */
 int svae_gru_fwd_range(const float* gi, const float* whh, const float* bhh, const int* row_off, const int* nact, int B,
                        int Tmax, int t0, int t1, float* hs, float* hprev, float* gates4, int prec, void* stream);
+/* svae_gru_bwd with dgh == NULL (bf16 kernel): dgi is ONE array [R][896] = (dr, dz, dn, dn*r) that carries both
+ * gradients (they only differ in the third gate); consumers: svae_rowgemm_ld / svae_wgrad_cols. */
 int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t, const int* row_off,
                  const int* nact, int B, int Tmax, float* dgi, float* dgh, int prec, void* stream);
 

@@ -32,6 +32,7 @@ struct RgArgs {
     const float* bias;            // [N] or nullptr
     float* y;                     // [R][N]
     int R, nrb;                   // rows, row blocks of 128
+    int ldx;                      // row stride of x (floats, >= K)
 };
 
 __device__ __forceinline__ unsigned rg_pk2(float a, float b) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
     const int ntc = (NT - c * CT) < CT ? (NT - c * CT) : CT;
     const int row = rb * RG_ROWS + wave * 32 + li;
     const bool rok = row < a.R;
-    const float* xr = a.x + (size_t)(rok ? row : a.R - 1) * K + 8 * lh;
+    const float* xr = a.x + (size_t)(rok ? row : a.R - 1) * a.ldx + 8 * lh;
 
     // weight fragments of the chunk: ntc * KS pieces of 1 KiB, wave w issues pieces w, w + 4, ...
     {
@@ -204,11 +205,20 @@ extern "C" int svae_rowgemm_prep(const float* wih, int which, void* frags, void*
 
 // which 0: y [R][672] = x [R][256] W_ih^T + bias (bias may be NULL);  which 1: y [R][256] = x [R][672] W_ih.
 // frags from svae_rowgemm_prep(which) of the current W_ih.  x and y 16-byte aligned, dense rows.
+extern "C" int svae_rowgemm_ld(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,
+                               void* stream);
 extern "C" int svae_rowgemm(const float* x, const void* frags, const float* bias, float* y, int R, int which,
                             void* stream) {
+    return svae_rowgemm_ld(x, which == 0 ? SV_E : SV_G, frags, bias, y, R, which, stream);
+}
+
+// The same with rows of x ldx floats apart (dL/demb reads (dr, dz, dn) out of the merged [R][896] gradient array).
+extern "C" int svae_rowgemm_ld(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,
+                               void* stream) {
     SV_CHECK_ARG(x && frags && y && R > 0 && (which == 0 || which == 1), "svae_rowgemm: bad arguments");
+    SV_CHECK_ARG(ldx >= (which == 0 ? SV_E : SV_G) && (ldx % 4) == 0, "svae_rowgemm: bad row stride %d", ldx);
     SV_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
                  "svae_rowgemm: operands must be 16-byte aligned");
-    RgArgs a{x, (const unsigned short*)frags, bias, y, R, 0};
+    RgArgs a{x, (const unsigned short*)frags, bias, y, R, 0, ldx};
     return which == 0 ? rg_launch<0>(a, (hipStream_t)stream) : rg_launch<1>(a, (hipStream_t)stream);
 }

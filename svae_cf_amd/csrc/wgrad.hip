@@ -26,6 +26,7 @@ struct WgradArgs {
     int R, N, K, ldy, ldx;
     int nx, ny, nz, tiles_per_split;
     long long slab_stride;
+    int remap_from, remap_add;   // dY columns >= remap_from are read remap_add columns further (both multiples of 4)
 };
 
 __device__ __forceinline__ unsigned pk2(float a, float b) {
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     // one piece = one wave-instruction = 2 tile rows x 128 columns; a tile is 8 pieces per operand, wave w
     // issues pieces w and w + 4 of both.  Columns beyond the operand's width fall into the next row (finite
     // garbage that only reaches output rows / columns that are never stored) or beyond the buffer (zeros).
-    const unsigned colA = (unsigned)(m0 + 4 * (lane & 31)) * 4u, colB = (unsigned)(n0 + 4 * (lane & 31)) * 4u;
+    const int ca = m0 + 4 * (lane & 31);
+    const unsigned colA = (unsigned)(ca + (ca >= a.remap_from ? a.remap_add : 0)) * 4u, colB = (unsigned)(n0 + 4 * (lane & 31)) * 4u;
     const unsigned rowl = (unsigned)(lane >> 5);
 #define SV_WG_STAGE(t_, st_)                                                                                   \
     {                                                                                                          \
@@ -153,16 +155,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // Split z of nsplit writes gW [N][K] at out + z*slab_stride and, when colsum != NULL, gb [N] at
 // colsum + z*slab_stride (colsum usually = out + N*K); sum the slabs with svae_reduce_slabs.
 // bf16 operands (rounded from fp32 on the fly), fp32 accumulation.
+extern "C" int svae_wgrad_cols(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
+                               int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream);
 extern "C" int svae_wgrad(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
                           int ldx, int nsplit, long long slab_stride, void* stream) {
+    return svae_wgrad_cols(dy, x, out, colsum, R, N, K, ldy, ldx, nsplit, slab_stride, N, 0, stream);
+}
+
+// The same with dY's logical column n read from stored column n + (n >= remap_from ? remap_add : 0): the GRU's
+// recurrent-weight gradient takes (dr, dz, dn*r) out of the merged [R][896] array (remap_from 448, remap_add 224).
+extern "C" int svae_wgrad_cols(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
+                               int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream) {
     SV_CHECK_ARG(dy && x && out, "svae_wgrad: null pointer");
+    SV_CHECK_ARG(remap_from >= 0 && remap_add >= 0 && (remap_from % 4) == 0 && (remap_add % 4) == 0 && N + remap_add <= ldy,
+                 "svae_wgrad_cols: bad column remap");
     SV_CHECK_ARG(R > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && (ldy % 4) == 0 && (ldx % 4) == 0,
                  "svae_wgrad: bad shape R=%d N=%d K=%d ldy=%d ldx=%d", R, N, K, ldy, ldx);
     SV_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0, "svae_wgrad: operands must be 16-byte aligned");
     SV_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || slab_stride >= (long long)N * K), "svae_wgrad: bad split");
     SV_CHECK_ARG((long long)R * ldy * 4 < (1ll << 32) && (long long)R * ldx * 4 < (1ll << 32),
                  "svae_wgrad: operand larger than a 4 GiB buffer descriptor");
-    WgradArgs a{dy, x, out, colsum, R, N, K, ldy, ldx, (K + WN - 1) / WN, (N + WM - 1) / WM, nsplit, 0, slab_stride};
+    WgradArgs a{dy, x, out, colsum, R, N, K, ldy, ldx, (K + WN - 1) / WN, (N + WM - 1) / WM, nsplit, 0, slab_stride,
+                remap_from, remap_add};
     const int ntiles = (R + WK - 1) / WK;
     a.tiles_per_split = (ntiles + nsplit - 1) / nsplit;
     const int gsize = a.nx * a.ny;

@@ -106,6 +106,7 @@ class SVAEEngine:
         self._loss_deferred = False
         self.time_split = os.environ.get("SVAE_TIME_SPLIT", "1") == "1"
         self.rowgemm = os.environ.get("SVAE_ROWGEMM", "1") == "1"
+        self.merged_dg = os.environ.get("SVAE_MERGED_DG", "1") == "1"
         # train_step only: the decoder.linear2 gradient work (weight-gradient sweep, its finish, the bucket's
         # all-reduce, Adam over the bucket, the bf16 operand copies of the new weights) runs on a stream of its own
         # and the step does not wait for it -- it finishes under the next step's embedding / input GEMM / first
@@ -174,7 +175,7 @@ class SVAEEngine:
             torch.cuda.current_stream().synchronize()
         cap = int(R * 1.25) + 64
         f32 = dict(device=self.device, dtype=torch.float32)
-        shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dgh=G, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
+        shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dgh=G, dg4=4 * HP, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
                       logits=self.IP, dz=L, dtmp=2 * L, dd1=DP, denc=DP, dhs=HP, dgi=G, demb=E,
                       kl_row=1, nll_row=1, lse=1)
         shapes["logits"] = 0                      # allocated on demand (_ensure_logits): fused mode never needs it
@@ -275,7 +276,7 @@ class SVAEEngine:
         self.side_stream_info.append(dict(tried=tries, all_us=times[best], concurrent=False))
         return cands[best]
 
-    def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx, slabs=None):
+    def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx, slabs=None, remap=None):
         """Weight + bias gradient of y = x W^T + b in one pass: gW[N][K] = dY[R][N]^T X[R][K] and
         gb[N] = column sums of dY (folded into the GEMM).  Split-K over rows writes one slab per split
         (weights then bias), summed in a fixed order: deterministic, no atomics.  The bias gradient sits
@@ -287,11 +288,13 @@ class SVAEEngine:
         stride = N * K + N
         if self.prec == PREC_BF16:
             ev = self._tic("wgrad")
+            rf, ra = remap if remap is not None else (N, 0)
             if ns == 1:
-                _lib.call("svae_wgrad", dY.data_ptr(), X.data_ptr(), out, out + 4 * N * K, R, N, K, ldy, ldx, 1, 0, _stream())
+                _lib.call("svae_wgrad_cols", dY.data_ptr(), X.data_ptr(), out, out + 4 * N * K, R, N, K, ldy, ldx, 1, 0,
+                          rf, ra, _stream())
             else:
-                _lib.call("svae_wgrad", dY.data_ptr(), X.data_ptr(), sp, sp + 4 * N * K, R, N, K, ldy, ldx, ns, stride,
-                          _stream())
+                _lib.call("svae_wgrad_cols", dY.data_ptr(), X.data_ptr(), sp, sp + 4 * N * K, R, N, K, ldy, ldx, ns, stride,
+                          rf, ra, _stream())
                 _lib.call("svae_reduce_slabs", sp, out, stride, ns, stride, _stream())
             self._toc("wgrad", ev)
             return
@@ -664,9 +667,14 @@ class SVAEEngine:
         if not prepped:
             _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
         ev = self._tic("gru_bwd")
+        # bf16 kernels: ONE gradient array [R][896] = (dr, dz, dn, dn*r) instead of dgi and dgh (they differ in the third
+        # gate only): a third fewer stores in every BPTT step
+        merged = self.fused and self.rowgemm and self.gru_prec == PREC_BF16 and self.merged_dg
+        dgi, ldg = (w["dg4"], 4 * HP) if merged else (w["dgi"], G)
+        dgh, hh_remap = (w["dg4"], (2 * HP, HP)) if merged else (w["dgh"], None)
         _lib.call("svae_gru_bwd", w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
                   self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
-                  w["dgi"].data_ptr(), w["dgh"].data_ptr(), self.gru_prec, st)
+                  dgi.data_ptr(), None if merged else dgh.data_ptr(), self.gru_prec, st)
         self._toc("gru_bwd", ev)
         if side is not None:
             # gated on the chain above, enqueued after the recurrence so that its few workgroups get their CUs
@@ -694,11 +702,11 @@ class SVAEEngine:
         def embedding_grad():
             if self.fused and self.rowgemm and prepped:
                 ev = self._tic("demb_gemm")
-                _lib.call("svae_rowgemm", w["dgi"].data_ptr(), self.wih_frags[1].data_ptr(), None, w["demb"].data_ptr(),
-                          R, 1, st)
+                _lib.call("svae_rowgemm_ld", dgi.data_ptr(), ldg, self.wih_frags[1].data_ptr(), None,
+                          w["demb"].data_ptr(), R, 1, st)
                 self._toc("demb_gemm", ev)
             else:
-                self._gemm(w["dgi"], self.P("gru.weight_ih_l0"), w["demb"], R, E, G, G, E, E, 0, 1)
+                self._gemm(dgi, self.P("gru.weight_ih_l0"), w["demb"], R, E, G, ldg, E, E, 0, 1)
             # embedding: dense gradient, zero + deterministic segmented scatter-add
             ge = self.Gv("item_embed.weight")
             if not prepped:
@@ -711,8 +719,8 @@ class SVAEEngine:
         def gru_wgrads():
             # (Tried: these two on a second side stream beside dL/demb -> scatter-add.  2.5 % SLOWER, 1.153 vs 1.123 ms
             # per step: the tail of backward is short of bandwidth, not of parallelism.)
-            self._wgrad(w["dgh"], w["hprev"], "gru.weight_hh_l0", R, G, HP, G, HP)
-            self._wgrad(w["dgi"], w["emb"], "gru.weight_ih_l0", R, G, E, G, E)
+            self._wgrad(dgh, w["hprev"], "gru.weight_hh_l0", R, G, HP, ldg, HP, remap=hh_remap)
+            self._wgrad(dgi, w["emb"], "gru.weight_ih_l0", R, G, E, ldg, E)
 
         if self.tail_embedding_first:
             embedding_grad()
