@@ -264,3 +264,51 @@ def test_rowgemm_matches_fp32_product_of_bf16_operands(R):
         ref = xb @ wb.t() + bias if which == 0 else xb @ wb
         err = float((y - ref).abs().max())
         assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, (which, R, err)
+
+
+def test_masked_topk_equals_stable_descending_sort_on_edge_cases():
+    """svae_masked_topk against torch.sort(descending=True, stable=True) of the masked scores (the reference's full
+    sort nb:632 with ties by lower item index): random rows, heavy ties (pre-filter overflows -> selection over all
+    scores), a constant row (more ties at the threshold than the LDS sort holds -> arg-max rounds), -inf entries,
+    K = 1 and K = I.  Bit-exact indices and values."""
+    from svae_cf_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(5)
+
+    def run(scores, seen_lists, K):
+        n, I = scores.shape
+        ld = (I + 3) // 4 * 4
+        buf = torch.zeros(n, ld)
+        buf[:, :I] = scores
+        buf = buf.cuda()
+        off = np.zeros(n + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(x) for x in seen_lists])
+        seen = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.int32) for x in seen_lists] + [np.zeros(1, np.int32)])).cuda()
+        off_t = torch.from_numpy(off).cuda()
+        idx = torch.empty(n * K, dtype=torch.int32, device="cuda")
+        val = torch.empty(n * K, device="cuda")
+        work = torch.empty_like(buf)
+        _lib.call("svae_masked_topk", buf.data_ptr(), ld, seen.data_ptr(), off_t.data_ptr(), n, I, K, idx.data_ptr(),
+                  val.data_ptr(), work.data_ptr(), st)
+        torch.cuda.synchronize()
+        ref = scores.clone()
+        for u, lst in enumerate(seen_lists):
+            for it in lst:
+                ref[u, it] = ref[u, it] - (ref[u, it] * 1.0).abs() * 1e8
+        rv, ri = torch.sort(ref, dim=1, descending=True, stable=True)
+        assert torch.equal(idx.view(n, K).cpu().long(), ri[:, :K]), "indices"
+        assert torch.equal(val.view(n, K).cpu(), rv[:, :K]), "values"
+
+    I = 5000
+    rnd = torch.randn(4, I, generator=g)
+    run(rnd, [[1, 7, 4999], [], list(range(0, 3000, 3)), [0]], 100)
+    few = torch.randint(0, 3, (3, I), generator=g).float()             # three distinct values: thousands of ties
+    run(few, [[], [5], [6, 7]], 100)
+    run(torch.full((2, I), 0.25), [[], [3]], 100)                       # constant rows
+    inf = rnd.clone()
+    inf[:, ::2] = float("-inf")
+    run(inf, [[], [], [], []], 100)
+    run(rnd, [[], [], [], []], 1)
+    small = torch.randn(3, 50, generator=g)
+    run(small, [[], [1], [2, 3]], 50)
+    run(torch.randn(2, 3000, generator=g), [[], []], 2000)             # K above the LDS sort: arg-max rounds

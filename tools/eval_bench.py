@@ -1,0 +1,76 @@
+"""Scoring throughput (evaluate()'s per-user work: forward with loss at anneal 0.2, last-step logits, seen-item
+mask, top-100) on the ML-20M shape, and the masked top-k kernel alone against its HBM roofline.
+
+    python tools/eval_bench.py [items] [batch]
+"""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import svae_cf_amd as S
+from svae_cf_amd import synth, _lib
+
+I = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+_, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+users = synth.make_users(8 * B, I, mu, sigma, lmax, seed=98765)
+batches = synth.bucketed_batches([len(u) for u in users], B, np.random.default_rng(98765))
+plans = [S.build_plan([users[i] for i in idx], 4, user_keys=idx, device="cuda", total_items=I) for idx in batches]
+eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+torch.manual_seed(0)
+eng.load_state_dict({n: torch.randn(s) * 0.05 for n, s in eng.layout.ref_shapes.items()})
+for p in plans:
+    eng.prepare(p)
+    eng.score(p, 100, seed=1)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 0
+for _ in range(3):
+    for p in plans:
+        eng.score(p, 100, seed=1)
+        n += p.B
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+# the top-k kernel alone
+st = torch.cuda.current_stream().cuda_stream
+p = plans[0]
+scores = torch.randn(B, eng.IP, device="cuda")
+work = torch.empty_like(scores)
+idx = torch.empty(B * 100, dtype=torch.int32, device="cuda")
+val = torch.empty(B * 100, device="cuda")
+args = (scores.data_ptr(), eng.IP, p.seen.data_ptr(), p.seen_off.data_ptr(), B, I, 100, idx.data_ptr(), val.data_ptr(),
+        work.data_ptr(), st)
+for _ in range(3):
+    _lib.call("svae_masked_topk", *args)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    _lib.call("svae_masked_topk", *args)
+e1.record()
+e1.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / 20
+# the same kernel over a larger scoring batch (8 plans' users at once: two workgroups per CU in flight)
+BB = 8 * B
+big = torch.randn(BB, eng.IP, device="cuda")
+bwork = torch.empty_like(big)
+seen_off = torch.cat([p.seen_off[:-1].to(torch.int64)] * 8 + [p.seen_off[-1:].to(torch.int64)]).to(torch.int32)   # reuse plan 0's lists
+seen_off = (torch.arange(BB + 1, device="cuda") % (B + 0) * 0).to(torch.int32)      # no seen items: mask cost is negligible
+bidx = torch.empty(BB * 100, dtype=torch.int32, device="cuda")
+bval = torch.empty(BB * 100, device="cuda")
+bargs = (big.data_ptr(), eng.IP, p.seen.data_ptr(), seen_off.data_ptr(), BB, I, 100, bidx.data_ptr(), bval.data_ptr(),
+         bwork.data_ptr(), st)
+for _ in range(3):
+    _lib.call("svae_masked_topk", *bargs)
+e0.record()
+for _ in range(10):
+    _lib.call("svae_masked_topk", *bargs)
+e1.record()
+e1.synchronize()
+us_big = e0.elapsed_time(e1) * 1e3 / 10
+ok = bool((torch.topk(big[:, :I], 100, dim=1).indices.to(torch.int32).reshape(-1) == bidx).all())
+algo = B * I * 4 + B * 100 * 8
+print(json.dumps({"metric": "users scored/s (ML-20M shape, top-100)", "value": n / dt, "batch": B, "items": I,
+                  "ms_per_batch": dt / (3 * len(plans)) * 1e3,
+                  "masked_topk": {"us": us, "algorithmic_bytes": algo, "GB/s": algo / us / 1e3,
+                                  "frac_of_8TB/s": algo / us / 1e3 / 8000.0},
+                  "masked_topk_2048_users": {"us": us_big, "GB/s": 8 * algo / us_big / 1e3,
+                                             "frac_of_8TB/s": 8 * algo / us_big / 1e3 / 8000.0, "equals_torch_topk": ok}}))
