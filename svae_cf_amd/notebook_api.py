@@ -435,3 +435,65 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=64
             key = "%s@%d" % (nm, kk)
             metrics[key] = round((100.0 * sums[key]) / total_users, 4)
     return metrics, len_map
+
+
+# --------------------------------------------------------------------------------------------
+# epoch driver (nb:1271-1307, nb:1366-1382): SURVEY 8f row 2
+# --------------------------------------------------------------------------------------------
+def _metrics_string(metrics, tag):
+    s = ""
+    for m in metrics:                                     # nb:1283 / nb:1289 / nb:1374
+        s += " | " + m + " = " + str(metrics[m])
+    return s + " (" + tag + ")"
+
+
+def fit(model, criterion, train_reader, val_reader, test_reader, hyper_params, optimizer=None, batch_size=None,
+        log=print, checkpoint_path=None, seed=0, grad_sync=None, rank=0, world=1):
+    """The notebook's epoch loop and final test evaluation (nb:1271-1307, nb:1366-1382) with its log lines:
+    per epoch train -> evaluate(train, first `train_cp_users` users) -> evaluate(val) -> the two
+    '| end of epoch' lines; the model with the best validation NDCG@100 so far (>=, nb:1303) is kept; at the end
+    it is restored and scored on the test reader ('| End of training ... (TEST)').
+
+    Differences, on purpose: the best model is kept as a ``state_dict`` (reference names and shapes; written to
+    ``checkpoint_path`` with torch.save when given) instead of a pickled module (nb:1304); ``batch_size`` switches
+    the per-epoch training from the notebook's per-user ``train`` to ``train_batched``.
+    Returns (test metrics, len_to_ndcg_at_100_map, best validation NDCG@100)."""
+    if optimizer is None and batch_size is None:
+        optimizer = Adam(model, weight_decay=hyper_params["weight_decay"])
+    best_val_ndcg, best_state = None, None
+    for epoch in range(1, hyper_params["epochs"] + 1):
+        epoch_start_time = time.time()
+        if batch_size is None:
+            train(train_reader, model, optimizer, criterion, hyper_params, epoch, log=log)
+        else:
+            train_batched(train_reader, model, hyper_params, batch_size=batch_size, epoch=epoch, seed=seed, log=log,
+                          grad_sync=grad_sync, rank=rank, world=world)
+        metrics, _ = evaluate(model, criterion, train_reader, hyper_params, True)
+        string = _metrics_string(metrics, "TRAIN")
+        metrics, _ = evaluate(model, criterion, val_reader, hyper_params, False)
+        string2 = _metrics_string(metrics, "VAL")
+        ss = "-" * 89
+        ss += "\n| end of epoch {:3d} | time: {:5.2f}s".format(epoch, (time.time() - epoch_start_time))
+        ss += string
+        ss += "\n"
+        ss += "-" * 89
+        ss += "\n| end of epoch {:3d} | time: {:5.2f}s".format(epoch, (time.time() - epoch_start_time))
+        ss += string2
+        ss += "\n"
+        ss += "-" * 89
+        log(ss)
+        if not best_val_ndcg or metrics["NDCG@100"] >= best_val_ndcg:          # nb:1303
+            best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            if checkpoint_path is not None:
+                torch.save(best_state, checkpoint_path)
+            best_val_ndcg = metrics["NDCG@100"]
+    if best_state is not None:
+        model.load_state_dict(best_state)                                       # nb:1367
+    metrics, len_to_ndcg_at_100_map = evaluate(model, criterion, test_reader, hyper_params, False)
+    ss = "=" * 89
+    ss += "\n| End of training"
+    ss += _metrics_string(metrics, "TEST")
+    ss += "\n"
+    ss += "=" * 89
+    log(ss)
+    return metrics, len_to_ndcg_at_100_map, best_val_ndcg

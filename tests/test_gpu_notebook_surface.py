@@ -110,3 +110,45 @@ def test_notebook_evaluate_matches_reference(golden_dir, name):
     assert sorted(len_map.keys()) == list(g["len_map_keys"])
     for kk in len_map:
         np.testing.assert_allclose(len_map[kk], g["len_map/%d" % kk], atol=1e-12)
+
+
+@pytest.mark.parametrize("batch_size", [None, 16])
+def test_fit_epoch_driver_log_lines_and_best_checkpoint(tmp_path, batch_size):
+    """Epoch driver (nb:1271-1307, nb:1366-1382): log-line formats the reference's plotting cell parses
+    (nb:1310-1347), best-validation selection with >=, restore before the test evaluation, state_dict checkpoint
+    with the reference's parameter names.  Per-user training (batch_size None) and the batched fast path."""
+    import re
+    from svae_cf_amd import notebook_api as N
+    from svae_cf_amd import synth
+    I = 120
+    users = synth.make_users(60, I, 2.6, 0.4, 40, seed=3)
+    tr, va, te = users[:40], users[40:50], users[50:]
+
+    def split(us):
+        return [u[:int(0.8 * len(u))] for u in us], [u[int(0.8 * len(u)):] for u in us]
+    hp = _hp(I, epochs=2, batch_log_interval=20, train_cp_users=8)
+    train_reader = N.DataReader(hp, _lines(tr), None, I, True)
+    vf, vh = split(va)
+    tf, th = split(te)
+    val_reader = N.DataReader(hp, _lines(vf), _lines(vh), I, False)
+    test_reader = N.DataReader(hp, _lines(tf), _lines(th), I, False)
+    torch.manual_seed(0)
+    model = N.Model(hp)
+    crit = N.VAELoss(hp, model)
+    logs = []
+    ckpt = str(tmp_path / "best.pt")
+    metrics, len_map, best = N.fit(model, crit, train_reader, val_reader, test_reader, hp, batch_size=batch_size,
+                                   log=logs.append, checkpoint_path=ckpt)
+    text = "\n".join(logs)
+    ends = re.findall(r"\| end of epoch +(\d+) \| time: +[\d.]+s \| loss = [\d.]+ \| NDCG@10 = [\d.]+ .*\((TRAIN|VAL)\)", text)
+    assert ends == [("1", "TRAIN"), ("1", "VAL"), ("2", "TRAIN"), ("2", "VAL")]
+    assert re.search(r"\| End of training \| loss = [\d.]+ \| NDCG@10 = .* \| Prec@100 = [\d.]+ \(TEST\)", text)
+    assert list(metrics.keys()) == ["loss", "NDCG@10", "Rec@10", "Prec@10", "NDCG@100", "Rec@100", "Prec@100"]
+    vals = [float(v) for v in re.findall(r"NDCG@100 = ([\d.]+) \| Rec@100 = [\d.]+ \| Prec@100 = [\d.]+ \(VAL\)", text)]
+    assert best == max(vals) and len(vals) == 2
+    sd = torch.load(ckpt, weights_only=True)
+    assert set(sd.keys()) == set(O.PARAM_NAMES)
+    now = model.state_dict()
+    for k in sd:                      # the best model was restored before the test evaluation
+        assert torch.equal(sd[k].cpu(), now[k].cpu()), k
+    assert all(np.isfinite(v) for v in metrics.values()) and sum(len(v) for v in len_map.values()) == len(te)
