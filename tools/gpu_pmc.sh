@@ -5,7 +5,7 @@
 # Output: gpurun_out/pmc_<tag>/<pass>/...counter_collection.csv and gpurun_out/pmc_<tag>.txt (summary).
 set -o pipefail
 TAG=${1:-x}
-FILT=${2:-proj_kernel}
+FILT=${2:-proj_kernel}   # "kernel" = every kernel
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
