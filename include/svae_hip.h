@@ -143,7 +143,8 @@ int svae_loss_reduce(const float* nll_row, const float* kl_row, const float* w_n
  * R_pad, I_pad: multiples of 64.  parts (bit mask, 3 = everything): 1 sweep kernel, 2 finish kernel -- the
  * split exists so a profiler can bracket one kernel.
  * Work division: every sweep takes a schedule built ONCE per shape by svae_proj_schedule (a HOST function:
- * nx resident rows -- R for _fwd / _fwd_dh, I for _bwd_dw -- ny streamed rows, ncu compute units; uniform = 1
+ * nx resident rows -- R for _fwd / _fwd_dh, I for _bwd_dw -- ny streamed rows, ncu compute units; uniform = 0:
+ * balanced form, nominal 8-way split; uniform = -n: balanced form with a nominal n-way split; uniform = 1
  * gives every x tile the same split count (for sweeps whose streamed operand outgrows the L2); writes 4 ints
  * per workgroup into HOST memory `sched`, room for cap >= svae_proj_ns_max() * ceil(nx/256) workgroups; returns
  * the workgroup count nwg, and ns_q / ns_rem: x tile j of 256 rows is split ns_q + (j < ns_rem) ways).  The

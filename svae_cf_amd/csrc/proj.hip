@@ -747,7 +747,7 @@ extern "C" int svae_proj_schedule(int nx, int ny, int ncu, int uniform, int* sch
     const int lim = nt < NS_MAX ? nt : NS_MAX;
     long long W;
     int q, rem = 0;
-    if (uniform) {
+    if (uniform > 0) {
         // every x tile split the same number of ways (the nominal 8, or uniform - 1 when uniform > 1): all
         // workgroups the same length, so the rounds stay aligned and the workgroups of an XCD walk Y in lockstep.
         // Needed when a split's part of Y (40 KiB per y tile) does not fit the XCD's 4 MiB L2: a workgroup that
@@ -758,7 +758,8 @@ extern "C" int svae_proj_schedule(int nx, int ny, int ncu, int uniform, int* sch
         if (q > lim) q = lim;
         W = (long long)q * xt;
     } else {
-        const long long nominal = (long long)NSPLIT * xt;
+        // uniform < 0: nominal split count -uniform instead of 8 (fewer, longer workgroups: fewer slabs)
+        const long long nominal = (long long)(uniform < 0 ? -uniform : NSPLIT) * xt;
         const long long rounds = (nominal + ncu - 1) / ncu;
         W = rounds * ncu;
         q = (int)(W / xt), rem = (int)(W % xt);

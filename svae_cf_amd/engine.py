@@ -517,7 +517,11 @@ class SVAEEngine:
         cache = plan.proj_sched
         if key not in cache:
             if side == "rows":
-                tab, q, rem = _lib.proj_schedule(plan.R if nx is None else nx, self.I, ncu, uniform=0)
+                # nominal 4-way split (the workgroup count is the next whole multiple of the CU count): fewer, longer
+                # workgroups than the 8-way nominal write and re-read fewer slabs -- measured 3: 243.8k, 4: 245.0k,
+                # 5: 243.2k, 6: 242.0k, 8: 240.1k seq/s
+                tab, q, rem = _lib.proj_schedule(plan.R if nx is None else nx, self.I, ncu,
+                                                 uniform=-int(os.environ.get("SVAE_FDH_Q0", "4")))
             else:
                 fq = int(os.environ.get("SVAE_DW_Q", "0"))
                 tab, q, rem = _lib.proj_schedule(self.I, plan.R, ncu, uniform=1 + fq if fq > 0 else 1)
@@ -689,14 +693,16 @@ class SVAEEngine:
                     self._bucket(0)
                 self._float_pending = True
             with _Launch(side, self._torch_ctx()):
-                if self._loss_deferred:
-                    _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(),
-                              plan.w_nll.data_ptr(), plan.w_kl.data_ptr(), float(anneal), R,
-                              self.loss_out.data_ptr(), _stream())
                 if not floating:
                     proj_dw(w["pslabs_side"])
                     self._bucket(0)
                 decoder_side_wgrads(self.slabs_side)
+                if self._loss_deferred:
+                    # last on this stream: a one-workgroup kernel that waited 40 us for a free CU beside the sweep
+                    # when it came first, with the weight gradients queued behind it
+                    _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(),
+                              plan.w_nll.data_ptr(), plan.w_kl.data_ptr(), float(anneal), R,
+                              self.loss_out.data_ptr(), _stream())
         # Order of the tail: the embedding gradient first.  Its bucket is the largest of the step (256 I floats) and
         # its all-reduce then runs under the GRU weight-gradient kernels; the GRU bucket that ends the step is 1.3 MB.
         def embedding_grad():
