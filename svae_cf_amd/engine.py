@@ -523,8 +523,11 @@ class SVAEEngine:
                 tab, q, rem = _lib.proj_schedule(plan.R if nx is None else nx, self.I, ncu,
                                                  uniform=-int(os.environ.get("SVAE_FDH_Q0", "4")))
             else:
-                fq = int(os.environ.get("SVAE_DW_Q", "0"))
-                tab, q, rem = _lib.proj_schedule(self.I, plan.R, ncu, uniform=1 + fq if fq > 0 else 1)
+                # uniform 4-way split.  With the sweep on its own stream past the end of the step, fewer and longer
+                # workgroups win (slab traffic): 2: 249.4k, 3: 248.9k, 4: 249.0k, 5: 247.6k, 6: 248.4k, 7: 245.1k,
+                # 8: 244.5k seq/s.  (Before the sweep floated, 8 was best: 3: -4 %, 4: -0.4 %.)
+                fq = int(os.environ.get("SVAE_DW_Q", "4"))
+                tab, q, rem = _lib.proj_schedule(self.I, plan.R, ncu, uniform=1 + fq)   # (ncu unused: uniform)
             cache[key] = (torch.from_numpy(tab).to(self.device), int(tab.shape[0]), q, rem)
         t, n, q, rem = cache[key]
         return (t.data_ptr(), n, q, rem)
