@@ -64,6 +64,10 @@ int svae_rowgemm(const float* x, const void* frags, const float* bias, float* y,
 int svae_rowgemm_ld(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,
                     void* stream);   /* rows of x ldx floats apart */
 
+int svae_rowgemm_bf16x(const void* x, int ldx, const void* frags, float* y, int R, void* stream);   /* which 1, bf16 x */
+int svae_wgrad_cols_bf16dy(const void* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
+                           int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream);
+
 /* ---- item embedding ----------------------------------------------------------------------------
  * svae_embed_fwd replaces self.item_embed(x) nb:756: out[r][:] = table[x[r]][:] (E = 256).
  * svae_embed_bwd replaces the embedding backward of loss.backward() nb:1205 as a deterministic
@@ -89,6 +93,9 @@ int svae_gru_fwd_range(const float* gi, const float* whh, const float* bhh, cons
                        int Tmax, int t0, int t1, float* hs, float* hprev, float* gates4, int prec, void* stream);
 /* svae_gru_bwd with dgh == NULL (bf16 kernel): dgi is ONE array [R][896] = (dr, dz, dn, dn*r) that carries both
  * gradients (they only differ in the third gate); consumers: svae_rowgemm_ld / svae_wgrad_cols. */
+/* the same with bf16 elements (every consumer rounds to bf16 anyway): svae_rowgemm_bf16x / svae_wgrad_cols_bf16dy */
+int svae_gru_bwd_bf16out(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
+                         const int* row_off, const int* nact, int B, int Tmax, void* dg4, void* stream);
 int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t, const int* row_off,
                  const int* nact, int B, int Tmax, float* dgi, float* dgh, int prec, void* stream);
 

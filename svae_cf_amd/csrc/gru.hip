@@ -70,6 +70,7 @@ struct GruArgs {
     float* dgh;           // [R][672]  (bwd out) d/d(gh) = (dr_pre, dz_pre, dn_pre * r)
     int B, Tmax;
     int merged;           // backward, bf16 kernel: dgi is ONE array [R][4*224] = (dr, dz, dn, dn*r); dgh is unused
+                          // (1: fp32 elements, 2: bf16 elements)
     int t0, t1;           // forward, bf16 kernel: timesteps [t0, t1) of the recurrence (t0 > 0: h_{t0-1} is read from hs)
 };
 
@@ -587,8 +588,10 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
     // differ in the third gate, so ONE array [R][896] = (dr, dz, dn, dn*r) carries both (its consumers read columns
     // 0..671, or 0..447 and 672..895): four stores per element instead of six, 39 MB less per step.
     const bool merged = a.merged != 0;
+    const bool out16 = a.merged == 2;      // bf16 elements: every consumer rounds to bf16 anyway (RNE here as there)
     const unsigned gld = merged ? 4u * SV_HP : (unsigned)SV_G;
-    const __amdgpu_buffer_rsrc_t gi_b = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, R * (gld * 4u), SV_BUF_FLAGS);
+    const unsigned gsz = out16 ? 2u : 4u;
+    const __amdgpu_buffer_rsrc_t gi_b = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, R * (gld * gsz), SV_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t gh_b = merged ? gi_b : __builtin_amdgcn_make_buffer_rsrc(a.dgh, 0, R * (SV_G * 4u), SV_BUF_FLAGS);
 
     // Element roles as in the forward kernel: lane 16 u + n owns user u of unit n of each tile this wave owns.
@@ -610,7 +613,7 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
         actv = lk < MU && u0 + lk < na_;                                                                    \
         ohs = actv ? (row * SV_HP + 16 * wave + ln) * 4u : SV_BUF_OOB;                                      \
         og4 = actv ? (row * SV_HP + 16 * wave + ln) * 16u : SV_BUF_OOB;                                     \
-        ogo = actv ? (row * gld + 16 * wave + ln) * 4u : SV_BUF_OOB;                                        \
+        ogo = actv ? (row * gld + 16 * wave + ln) * gsz : SV_BUF_OOB;                                       \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                    \
             sg[q] = __builtin_amdgcn_raw_buffer_load_b128(g4_b, og4 + 2048 * q, 0, 0);                      \
             shp[q] = __builtin_amdgcn_raw_buffer_load_b32(hp_b, ohs + 512 * q, 0, 0);                       \
@@ -634,15 +637,22 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
             const float drp = dnp * ghn * rg * (1.0f - rg);
             const float dnr = dnp * rg;
             carry[q] = d * zg;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gi_b, ogo + 512 * q, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gi_b, ogo + 512 * q + SV_HP * 4, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnp), gi_b, ogo + 512 * q + 2 * SV_HP * 4, 0, 0);
-            if (merged) {      // wave-uniform
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnr), gi_b, ogo + 512 * q + 3 * SV_HP * 4, 0, 0);
+            if (out16) {       // wave-uniform
+                __builtin_amdgcn_raw_buffer_store_b16(sv_f2bf(drp), gi_b, ogo + 256 * q, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(sv_f2bf(dzp), gi_b, ogo + 256 * q + SV_HP * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(sv_f2bf(dnp), gi_b, ogo + 256 * q + 2 * SV_HP * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(sv_f2bf(dnr), gi_b, ogo + 256 * q + 3 * SV_HP * 2, 0, 0);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gh_b, ogo + 512 * q, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gh_b, ogo + 512 * q + SV_HP * 4, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnr), gh_b, ogo + 512 * q + 2 * SV_HP * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gi_b, ogo + 512 * q, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gi_b, ogo + 512 * q + SV_HP * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnp), gi_b, ogo + 512 * q + 2 * SV_HP * 4, 0, 0);
+                if (merged) {      // wave-uniform
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnr), gi_b, ogo + 512 * q + 3 * SV_HP * 4, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(drp), gh_b, ogo + 512 * q, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dzp), gh_b, ogo + 512 * q + SV_HP * 4, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnr), gh_b, ogo + 512 * q + 2 * SV_HP * 4, 0, 0);
+                }
             }
             if (lk < MU) {   // MU = 4: every lane owns an image row
                 gcur[lk * GLDB + j] = sv_f2bf(drp);
@@ -749,13 +759,24 @@ extern "C" int svae_gru_fwd_range(const float* gi, const float* whh, const float
     return 0;
 }
 
+extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
+                            const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dgh,
+                            int prec, void* stream);
+// bf16 kernel with the merged gradient array as bf16 elements: dg4 [R][896] bf16 = (dr, dz, dn, dn*r).
+extern "C" int svae_gru_bwd_bf16out(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
+                                    const int* row_off, const int* nact, int B, int Tmax, void* dg4, void* stream) {
+    return svae_gru_bwd(dhs, hprev, gates4, whh_t, row_off, nact, B, Tmax, (float*)dg4, nullptr, 3, stream);
+}
+
 // Reference interface replaced: autograd through nn.GRU at loss.backward() (nb:1205).
 // whh_t is W_hh transposed, [224][672].
 extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
                             const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dgh,
                             int prec, void* stream) {
     // dgh == NULL (bf16 kernel only): merged output, dgi is [R][896] = (dr, dz, dn, dn*r)
-    const int merged = dgh == nullptr ? 1 : 0;
+    const int out16 = prec == 3 ? 1 : 0;      // internal: svae_gru_bwd_bf16out
+    if (out16) prec = 1;
+    const int merged = dgh == nullptr ? 1 + out16 : 0;
     GruArgs a{nullptr, whh_t, nullptr, row_off, nact, nullptr, const_cast<float*>(hprev),
               const_cast<float*>(gates4), dhs, dgi, merged ? dgi : dgh, B, Tmax, merged, 0, Tmax};
     if (int e = check_gru(a, true)) return e;

@@ -61,7 +61,8 @@ __device__ __forceinline__ void rg_glds16(const char* g, char* l) {
 //  SIMD, every block of 32 MFMAs waiting for a 1-2 us DMA issued two blocks earlier: 35 us however few rows.)
 // Grid: id -> (row block, chunk) with the chunks of a row block 8 ids apart, i.e. on the same XCD (id % 8) and
 // dispatched together: the row block is then read from HBM once and from that XCD's L2 by the other chunks.
-template <int WHICH>
+// XB: x holds bf16 elements (ldx in elements): a k-step of a lane is one 16-byte load and needs no conversion.
+template <int WHICH, bool XB>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
     using S = RgShape<WHICH>;
     constexpr int K = S::K, N = S::N, CT = S::CT, XG = S::XG, PDX = S::PDX;
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
     const int ntc = (NT - c * CT) < CT ? (NT - c * CT) : CT;
     const int row = rb * RG_ROWS + wave * 32 + li;
     const bool rok = row < a.R;
-    const float* xr = a.x + (size_t)(rok ? row : a.R - 1) * a.ldx + 8 * lh;
+    const float* xr = XB ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.x) +
+                                                           (size_t)(rok ? row : a.R - 1) * a.ldx + 8 * lh)
+                         : a.x + (size_t)(rok ? row : a.R - 1) * a.ldx + 8 * lh;
 
     // weight fragments of the chunk: ntc * KS pieces of 1 KiB, wave w issues pieces w, w + 4, ...
     {
@@ -87,11 +90,15 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
         const int npieces = ntc * KS;
         for (int p = wave; p < npieces; p += 4) rg_glds16(src + (size_t)p * 1024, wst + p * 1024);
     }
-    float4 xraw[PDX + 1][XG][2];
+    float4 xraw[PDX + 1][XG][XB ? 1 : 2];
 #define RG_LOADX(g_)                                                                                         \
     _Pragma("unroll") for (int s_ = 0; s_ < XG; ++s_) {                                                      \
-        xraw[(g_) % (PDX + 1)][s_][0] = *reinterpret_cast<const float4*>(xr + 16 * ((g_) * XG + s_));        \
-        xraw[(g_) % (PDX + 1)][s_][1] = *reinterpret_cast<const float4*>(xr + 16 * ((g_) * XG + s_) + 4);    \
+        if (XB) {   /* 16 bf16 per k-step = 8 floats' worth of address */                                    \
+            xraw[(g_) % (PDX + 1)][s_][0] = *reinterpret_cast<const float4*>(xr + 8 * ((g_) * XG + s_));     \
+        } else {                                                                                             \
+            xraw[(g_) % (PDX + 1)][s_][0] = *reinterpret_cast<const float4*>(xr + 16 * ((g_) * XG + s_));    \
+            xraw[(g_) % (PDX + 1)][s_][1] = *reinterpret_cast<const float4*>(xr + 16 * ((g_) * XG + s_) + 4);\
+        }                                                                                                    \
     }
 #pragma unroll
     for (int g = 0; g < PDX && g < NG; ++g) RG_LOADX(g)
@@ -115,10 +122,15 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
             if (g + PDX < NG) RG_LOADX(g + PDX)
 #pragma unroll
             for (int s = 0; s < XG; ++s) {
-                const float4 lo = xraw[g % (PDX + 1)][s][0], hi = xraw[g % (PDX + 1)][s][1];
-                uint4 u;
-                u.x = rg_pk2(lo.x, lo.y); u.y = rg_pk2(lo.z, lo.w); u.z = rg_pk2(hi.x, hi.y); u.w = rg_pk2(hi.z, hi.w);
-                const bf16x8 xf = __builtin_bit_cast(bf16x8, u);
+                bf16x8 xf;
+                if (XB) {
+                    xf = __builtin_bit_cast(bf16x8, xraw[g % (PDX + 1)][s][0]);
+                } else {
+                    const float4 lo = xraw[g % (PDX + 1)][s][0], hi = xraw[g % (PDX + 1)][s][1];
+                    uint4 u;
+                    u.x = rg_pk2(lo.x, lo.y); u.y = rg_pk2(lo.z, lo.w); u.z = rg_pk2(hi.x, hi.y); u.w = rg_pk2(hi.z, hi.w);
+                    xf = __builtin_bit_cast(bf16x8, u);
+                }
                 const int ks = g * XG + s;
 #pragma unroll
                 for (int t = 0; t < NTC; ++t) {
@@ -166,20 +178,20 @@ __global__ void rowgemm_prep_kernel(const float* __restrict__ src, int sn, int s
     (void)NT;
 }
 
-template <int WHICH>
+template <int WHICH, bool XB>
 int rg_launch(RgArgs a, hipStream_t st) {
     using S = RgShape<WHICH>;
     constexpr int lds = S::CT * (S::K / 16) * 1024;
     constexpr int nch = (S::N / 32 + S::CT - 1) / S::CT;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)rowgemm_kernel<WHICH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)rowgemm_kernel<WHICH, XB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_rowgemm: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     a.nrb = (a.R + RG_ROWS - 1) / RG_ROWS;
     const int groups = (a.nrb + 7) / 8;                 // 8 row blocks (one per XCD) x nch chunks each
-    hipLaunchKernelGGL(rowgemm_kernel<WHICH>, dim3(groups * nch * 8), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((rowgemm_kernel<WHICH, XB>), dim3(groups * nch * 8), dim3(256), lds, st, a);
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -220,5 +232,13 @@ extern "C" int svae_rowgemm_ld(const float* x, int ldx, const void* frags, const
     SV_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
                  "svae_rowgemm: operands must be 16-byte aligned");
     RgArgs a{x, (const unsigned short*)frags, bias, y, R, 0, ldx};
-    return which == 0 ? rg_launch<0>(a, (hipStream_t)stream) : rg_launch<1>(a, (hipStream_t)stream);
+    return which == 0 ? rg_launch<0, false>(a, (hipStream_t)stream) : rg_launch<1, false>(a, (hipStream_t)stream);
+}
+
+// which 1 with x as bf16 elements (the GRU's merged gradient array): ldx in elements, a multiple of 8.
+extern "C" int svae_rowgemm_bf16x(const void* x, int ldx, const void* frags, float* y, int R, void* stream) {
+    SV_CHECK_ARG(x && frags && y && R > 0 && ldx >= SV_G && (ldx % 8) == 0, "svae_rowgemm_bf16x: bad arguments");
+    SV_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "svae_rowgemm_bf16x: operands must be 16-byte aligned");
+    RgArgs a{(const float*)x, (const unsigned short*)frags, nullptr, y, R, 0, ldx};
+    return rg_launch<1, true>(a, (hipStream_t)stream);
 }

@@ -34,6 +34,9 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
+// ABF: dY holds bf16 elements (the GRU's merged gradient array): its tile is 16 rows x 128 columns x 2 B = 4 KiB, one
+// LDS-DMA piece (4 rows) per wave, and a fragment is built from 2-byte reads without conversion.
+template <bool ABF>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -51,22 +54,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     int t_end = t_begin + a.tiles_per_split;
     if (t_end > ntiles) t_end = ntiles;
 
-    const __amdgpu_buffer_rsrc_t dyb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((size_t)a.R * a.ldy * 4), BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t dyb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((size_t)a.R * a.ldy * (ABF ? 2 : 4)), BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((size_t)a.R * a.ldx * 4), BUF_FLAGS);
     // one piece = one wave-instruction = 2 tile rows x 128 columns; a tile is 8 pieces per operand, wave w
     // issues pieces w and w + 4 of both.  Columns beyond the operand's width fall into the next row (finite
     // garbage that only reaches output rows / columns that are never stored) or beyond the buffer (zeros).
-    const int ca = m0 + 4 * (lane & 31);
-    const unsigned colA = (unsigned)(ca + (ca >= a.remap_from ? a.remap_add : 0)) * 4u, colB = (unsigned)(n0 + 4 * (lane & 31)) * 4u;
+    const int ca = ABF ? m0 + 8 * (lane & 15) : m0 + 4 * (lane & 31);
+    const unsigned colA = (unsigned)(ca + (ca >= a.remap_from ? a.remap_add : 0)) * (ABF ? 2u : 4u), colB = (unsigned)(n0 + 4 * (lane & 31)) * 4u;
     const unsigned rowl = (unsigned)(lane >> 5);
+    const unsigned rowa = (unsigned)(lane >> 4);      // ABF: row of the lane inside its 4-row piece
 #define SV_WG_STAGE(t_, st_)                                                                                   \
     {                                                                                                          \
         char* l_ = smem + (st_) * STAGE_BYTES + wave * 1024;                                                    \
         const unsigned r0_ = (unsigned)(t_) * WK + 2 * wave + rowl;                                             \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)l_, 16,          \
-                                                 r0_ * (unsigned)a.ldy * 4u + colA, 0, 0, 0);                   \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)(l_ + 4096), 16, \
-                                                 (r0_ + 8) * (unsigned)a.ldy * 4u + colA, 0, 0, 0);             \
+        if (ABF) {                                                                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)l_, 16,      \
+                                                     ((unsigned)(t_) * WK + 4 * wave + rowa) * (unsigned)a.ldy * 2u + colA, 0, 0, 0); \
+        } else {                                                                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)l_, 16,      \
+                                                     r0_ * (unsigned)a.ldy * 4u + colA, 0, 0, 0);               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)(l_ + 4096), 16, \
+                                                     (r0_ + 8) * (unsigned)a.ldy * 4u + colA, 0, 0, 0);         \
+        }                                                                                                      \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES), 16, \
                                                  r0_ * (unsigned)a.ldx * 4u + colB, 0, 0, 0);                   \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES + 4096), 16, \
@@ -92,8 +101,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     for (int t = t_begin; t < t_end; ++t) {
         const int st = (t - t_begin) & (NST - 1);
         // own pieces of tile t landed (tiles t+1, t+2 may still be in flight: 8 younger pieces)
-        if (t + 2 < t_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // (pieces per tile and wave: 2 + 2, or 1 + 2 with a bf16 dY)
+        if (t + 2 < t_end) { if (ABF) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else if (t + 1 < t_end) { if (ABF) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();       // tile t complete; everyone is done reading tile t-1's stage
@@ -101,18 +111,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         if (t + NST - 1 < t_end) SV_WG_STAGE(t + NST - 1, (st + NST - 1) & (NST - 1))
         const float* sA = reinterpret_cast<const float*>(smem + st * STAGE_BYTES);
         const float* sB = sA + WK * WM;
+        const unsigned short* sAh = reinterpret_cast<const unsigned short*>(sA);
         if (do_cs) {
 #pragma unroll
-            for (int k = 0; k < WK; ++k) cs += sA[k * WM + tid];
+            for (int k = 0; k < WK; ++k) cs += ABF ? sv_bf2f(sAh[k * WM + tid]) : sA[k * WM + tid];
         }
         // fragment of a 32-column group: lane (li, lh) takes rows 8 lh .. 8 lh + 7 of column base + li
         bf16x8 fa[2], fb[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float* p = sA + (8 * lh) * WM + wm + 32 * i + li;
             uint4 u;
-            u.x = pk2(p[0], p[WM]); u.y = pk2(p[2 * WM], p[3 * WM]);
-            u.z = pk2(p[4 * WM], p[5 * WM]); u.w = pk2(p[6 * WM], p[7 * WM]);
+            if (ABF) {
+                const unsigned short* p = sAh + (8 * lh) * WM + wm + 32 * i + li;
+                u.x = (unsigned)p[0] | ((unsigned)p[WM] << 16); u.y = (unsigned)p[2 * WM] | ((unsigned)p[3 * WM] << 16);
+                u.z = (unsigned)p[4 * WM] | ((unsigned)p[5 * WM] << 16); u.w = (unsigned)p[6 * WM] | ((unsigned)p[7 * WM] << 16);
+            } else {
+                const float* p = sA + (8 * lh) * WM + wm + 32 * i + li;
+                u.x = pk2(p[0], p[WM]); u.y = pk2(p[2 * WM], p[3 * WM]);
+                u.z = pk2(p[4 * WM], p[5 * WM]); u.w = pk2(p[6 * WM], p[7 * WM]);
+            }
             fa[i] = __builtin_bit_cast(bf16x8, u);
         }
 #pragma unroll
@@ -164,14 +181,30 @@ extern "C" int svae_wgrad(const float* dy, const float* x, float* out, float* co
 
 // The same with dY's logical column n read from stored column n + (n >= remap_from ? remap_add : 0): the GRU's
 // recurrent-weight gradient takes (dr, dz, dn*r) out of the merged [R][896] array (remap_from 448, remap_add 224).
+static int wgrad_launch(const void* dy, int dy_bf16, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
+                        int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream);
 extern "C" int svae_wgrad_cols(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
                                int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream) {
+    return wgrad_launch(dy, 0, x, out, colsum, R, N, K, ldy, ldx, nsplit, slab_stride, remap_from, remap_add, stream);
+}
+// dy holds bf16 elements (ldy in elements, a multiple of 8; remap_from / remap_add multiples of 8).
+extern "C" int svae_wgrad_cols_bf16dy(const void* dy, const float* x, float* out, float* colsum, int R, int N, int K,
+                                      int ldy, int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add,
+                                      void* stream) {
+    SV_CHECK_ARG((ldy % 8) == 0 && (remap_from % 8) == 0 && (remap_add % 8) == 0, "svae_wgrad_cols_bf16dy: bad alignment");
+    return wgrad_launch(dy, 1, x, out, colsum, R, N, K, ldy, ldx, nsplit, slab_stride, remap_from, remap_add, stream);
+}
+
+static int wgrad_launch(const void* dy_, int dy_bf16, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
+                        int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream) {
+    const float* dy = (const float*)dy_;
     SV_CHECK_ARG(dy && x && out, "svae_wgrad: null pointer");
     SV_CHECK_ARG(remap_from >= 0 && remap_add >= 0 && (remap_from % 4) == 0 && (remap_add % 4) == 0 && N + remap_add <= ldy,
                  "svae_wgrad_cols: bad column remap");
     SV_CHECK_ARG(R > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && (ldy % 4) == 0 && (ldx % 4) == 0,
                  "svae_wgrad: bad shape R=%d N=%d K=%d ldy=%d ldx=%d", R, N, K, ldy, ldx);
     SV_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0, "svae_wgrad: operands must be 16-byte aligned");
+    (void)dy_bf16;   // the 4 GiB limit below is checked for the wider (fp32) element
     SV_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || slab_stride >= (long long)N * K), "svae_wgrad: bad split");
     SV_CHECK_ARG((long long)R * ldy * 4 < (1ll << 32) && (long long)R * ldx * 4 < (1ll << 32),
                  "svae_wgrad: operand larger than a 4 GiB buffer descriptor");
@@ -182,12 +215,18 @@ extern "C" int svae_wgrad_cols(const float* dy, const float* x, float* out, floa
     const int gsize = a.nx * a.ny;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
         if (e != hipSuccess) return svae_fail((int)e, "svae_wgrad: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
-                       (hipStream_t)stream, a);
+    if (dy_bf16)
+        hipLaunchKernelGGL(wgrad_kernel<true>, dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
+                           (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<false>, dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
+                           (hipStream_t)stream, a);
     SV_LAUNCH_CHECK();
     return 0;
 }

@@ -107,6 +107,7 @@ class SVAEEngine:
         self.time_split = os.environ.get("SVAE_TIME_SPLIT", "1") == "1"
         self.rowgemm = os.environ.get("SVAE_ROWGEMM", "1") == "1"
         self.merged_dg = os.environ.get("SVAE_MERGED_DG", "1") == "1"
+        self.dg_bf16 = os.environ.get("SVAE_DG_BF16", "1") == "1"
         # train_step only: the decoder.linear2 gradient work (weight-gradient sweep, its finish, the bucket's
         # all-reduce, Adam over the bucket, the bf16 operand copies of the new weights) runs on a stream of its own
         # and the step does not wait for it -- it finishes under the next step's embedding / input GEMM / first
@@ -185,6 +186,7 @@ class SVAEEngine:
             bf = dict(device=self.device, dtype=torch.bfloat16)
             capp = (cap + 63) // 64 * 64
             self.capp = capp
+            self.ws["dg4b"] = torch.zeros((cap + 1) * 4 * HP, **bf)
             self.ws["h2b"] = torch.zeros(capp * DP, **bf)
             self.ws["h2s"] = torch.zeros(capp * DP, **bf)
             self.ws["h2tb"] = torch.zeros(DP * capp, **bf)
@@ -276,7 +278,7 @@ class SVAEEngine:
         self.side_stream_info.append(dict(tried=tries, all_us=times[best], concurrent=False))
         return cands[best]
 
-    def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx, slabs=None, remap=None):
+    def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx, slabs=None, remap=None, dy_bf16=False):
         """Weight + bias gradient of y = x W^T + b in one pass: gW[N][K] = dY[R][N]^T X[R][K] and
         gb[N] = column sums of dY (folded into the GEMM).  Split-K over rows writes one slab per split
         (weights then bias), summed in a fixed order: deterministic, no atomics.  The bias gradient sits
@@ -288,12 +290,13 @@ class SVAEEngine:
         stride = N * K + N
         if self.prec == PREC_BF16:
             ev = self._tic("wgrad")
-            rf, ra = remap if remap is not None else (N, 0)
+            rf, ra = remap if remap is not None else (N if not dy_bf16 else (N + 7) // 8 * 8, 0)
+            fn = "svae_wgrad_cols_bf16dy" if dy_bf16 else "svae_wgrad_cols"
             if ns == 1:
-                _lib.call("svae_wgrad_cols", dY.data_ptr(), X.data_ptr(), out, out + 4 * N * K, R, N, K, ldy, ldx, 1, 0,
+                _lib.call(fn, dY.data_ptr(), X.data_ptr(), out, out + 4 * N * K, R, N, K, ldy, ldx, 1, 0,
                           rf, ra, _stream())
             else:
-                _lib.call("svae_wgrad_cols", dY.data_ptr(), X.data_ptr(), sp, sp + 4 * N * K, R, N, K, ldy, ldx, ns, stride,
+                _lib.call(fn, dY.data_ptr(), X.data_ptr(), sp, sp + 4 * N * K, R, N, K, ldy, ldx, ns, stride,
                           rf, ra, _stream())
                 _lib.call("svae_reduce_slabs", sp, out, stride, ns, stride, _stream())
             self._toc("wgrad", ev)
@@ -677,11 +680,21 @@ class SVAEEngine:
         # bf16 kernels: ONE gradient array [R][896] = (dr, dz, dn, dn*r) instead of dgi and dgh (they differ in the third
         # gate only): a third fewer stores in every BPTT step
         merged = self.fused and self.rowgemm and self.gru_prec == PREC_BF16 and self.merged_dg
-        dgi, ldg = (w["dg4"], 4 * HP) if merged else (w["dgi"], G)
-        dgh, hh_remap = (w["dg4"], (2 * HP, HP)) if merged else (w["dgh"], None)
-        _lib.call("svae_gru_bwd", w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
-                  self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
-                  dgi.data_ptr(), None if merged else dgh.data_ptr(), self.gru_prec, st)
+        # ... and as bf16 elements: its three MFMA consumers round it to bf16 anyway (RNE there as here), so the weight
+        # and embedding gradients are bit-identical and the array is written once and read three times at half the
+        # bytes; only the two GRU bias gradients (column sums of the array) see the rounding, 2e-4 relative
+        # (tests/test_gpu_fullsize.py::test_gru_gradient_array_forms_agree)
+        dg16 = merged and self.dg_bf16 and prepped
+        dgi, ldg = (w["dg4b"] if dg16 else w["dg4"], 4 * HP) if merged else (w["dgi"], G)
+        dgh, hh_remap = (dgi, (2 * HP, HP)) if merged else (w["dgh"], None)
+        if dg16:
+            _lib.call("svae_gru_bwd_bf16out", w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
+                      self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
+                      dgi.data_ptr(), st)
+        else:
+            _lib.call("svae_gru_bwd", w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
+                      self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
+                      dgi.data_ptr(), None if merged else dgh.data_ptr(), self.gru_prec, st)
         self._toc("gru_bwd", ev)
         if side is not None:
             # gated on the chain above, enqueued after the recurrence so that its few workgroups get their CUs
@@ -711,8 +724,12 @@ class SVAEEngine:
         def embedding_grad():
             if self.fused and self.rowgemm and prepped:
                 ev = self._tic("demb_gemm")
-                _lib.call("svae_rowgemm_ld", dgi.data_ptr(), ldg, self.wih_frags[1].data_ptr(), None,
-                          w["demb"].data_ptr(), R, 1, st)
+                if dg16:
+                    _lib.call("svae_rowgemm_bf16x", dgi.data_ptr(), ldg, self.wih_frags[1].data_ptr(),
+                              w["demb"].data_ptr(), R, st)
+                else:
+                    _lib.call("svae_rowgemm_ld", dgi.data_ptr(), ldg, self.wih_frags[1].data_ptr(), None,
+                              w["demb"].data_ptr(), R, 1, st)
                 self._toc("demb_gemm", ev)
             else:
                 self._gemm(dgi, self.P("gru.weight_ih_l0"), w["demb"], R, E, G, ldg, E, E, 0, 1)
@@ -728,8 +745,8 @@ class SVAEEngine:
         def gru_wgrads():
             # (Tried: these two on a second side stream beside dL/demb -> scatter-add.  2.5 % SLOWER, 1.153 vs 1.123 ms
             # per step: the tail of backward is short of bandwidth, not of parallelism.)
-            self._wgrad(dgh, w["hprev"], "gru.weight_hh_l0", R, G, HP, ldg, HP, remap=hh_remap)
-            self._wgrad(dgi, w["emb"], "gru.weight_ih_l0", R, G, E, ldg, E)
+            self._wgrad(dgh, w["hprev"], "gru.weight_hh_l0", R, G, HP, ldg, HP, remap=hh_remap, dy_bf16=dg16)
+            self._wgrad(dgi, w["emb"], "gru.weight_ih_l0", R, G, E, ldg, E, dy_bf16=dg16)
 
         if self.tail_embedding_first:
             embedding_grad()

@@ -137,3 +137,34 @@ def test_bf16_scoring_loss_matches_oracle():
     out = eng.score(plan, 10, eps=eps)[0]
     torch.cuda.synchronize()
     assert abs(float(out[0]) - loss_ref) <= 1e-3 * abs(loss_ref)
+
+
+def test_gru_gradient_array_forms_agree():
+    """The BPTT kernel can hand its gate gradients over as two fp32 arrays (dgi, dgh), as one merged fp32 array
+    (dr, dz, dn, dn*r) or as that array in bf16.  Every MFMA consumer rounds them to bf16 (RNE) before multiplying,
+    so the three forms must give BIT-IDENTICAL weight and embedding gradients; the two GRU bias gradients are column
+    sums of the array itself and differ by the bf16 rounding of their terms in the third form (<= 1e-3 of the
+    largest entry; measured 2e-4)."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    I, B = 3000, 64
+    users = synth.make_users(B, I, 3.6, 0.6, 120, seed=11)
+    plan = S.build_plan(users, 4, user_keys=np.arange(B), device="cuda", total_items=I)
+    grads = []
+    for merged, bf16 in ((False, False), (True, False), (True, True)):
+        eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+        torch.manual_seed(1)
+        eng.load_state_dict({n: torch.randn(s) * 0.1 for n, s in eng.layout.ref_shapes.items()})
+        eng.merged_dg, eng.dg_bf16 = merged, bf16
+        eng.forward(plan, 0.05, seed=3, step=1)
+        eng.backward()
+        torch.cuda.synchronize()
+        grads.append(eng.grad_dict())
+    for k in grads[0]:
+        assert float(grads[0][k].abs().max()) > 0, k
+        assert torch.equal(grads[0][k], grads[1][k]), ("merged fp32 array", k)
+        if k in ("gru.bias_ih_l0", "gru.bias_hh_l0"):
+            d = float((grads[1][k] - grads[2][k]).abs().max())
+            assert d <= 1e-3 * float(grads[1][k].abs().max()), (k, d)
+        else:
+            assert torch.equal(grads[1][k], grads[2][k]), ("merged bf16 array", k)
