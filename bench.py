@@ -205,8 +205,8 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     for tag, r in rooflines.items():
-        if tag in pmc and "hbm_bytes" in pmc[tag]:
-            r["traffic"] = pmc[tag]["hbm_bytes"]
+        if tag in pmc and "hbm_bytes" in pmc[tag]:      # per STEP, like avg_ms: bytes per launch x launches per step
+            r["traffic"] = pmc[tag]["hbm_bytes"] * pmc[tag].get("launches_per_step", 1.0)
     # The dominant kernel is the projection sweep, proj_kernel<MODE> (csrc/proj.hip): launched twice per step
     # (forward + dL/dh sweep, dL/dW sweep), together the largest share of the step.  Its line covers both
     # launches: 4 projection-sized contractions per step over the sum of the two durations.  The GRU recurrence

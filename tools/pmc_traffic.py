@@ -21,7 +21,10 @@ def per_kernel(path):
         k = r["Kernel_Name"]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k].add(r["Dispatch_Id"])
-    return {k: {c: v / len(calls[k]) for c, v in cs.items()} for k, cs in acc.items()}
+    out = {k: {c: v / len(calls[k]) for c, v in cs.items()} for k, cs in acc.items()}
+    for k in out:
+        out[k]["_dispatches"] = float(len(calls[k]))
+    return out
 
 
 def main():
@@ -38,6 +41,8 @@ def main():
             continue
         mode = {"<0>": "proj_fwd", "<1>": "proj_fdh_fused", "<2>": "proj_dw_fused"}[k[k.index("<"):k.index(">") + 1]]
         d = dict(cs)
+        steps = max((c.get("_dispatches", 0.0) for kk, c in merged.items() if "proj_kernel<2>" in kk), default=0.0)
+        d["launches_per_step"] = d.pop("_dispatches", 0.0) / steps if steps else 1.0
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             d["hbm_read_bytes"] = 2.0 * cs["FETCH_SIZE"] * 1024.0
             d["hbm_write_bytes"] = cs["WRITE_SIZE"] * 1024.0
@@ -50,7 +55,7 @@ def main():
         out[mode] = d
     json.dump({"source": src, "note": "per-launch averages over a 4-step bench run; see tools/pmc_traffic.py for the corrections",
                "kernels": out}, open(dst, "w"), indent=1, sort_keys=True)
-    print(json.dumps({m: {k: d.get(k) for k in ("hbm_bytes", "mfma_pipe_util", "l2_hit_rate")} for m, d in out.items()}))
+    print(json.dumps({m: {k: d.get(k) for k in ("hbm_bytes", "launches_per_step", "mfma_pipe_util", "l2_hit_rate")} for m, d in out.items()}))
 
 
 if __name__ == "__main__":
