@@ -404,6 +404,16 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
     unsigned long long ts_last = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
+    float gi_nx[NQ][3];          // input-side gates of the step about to run
+    {
+        const bool act0 = lk < MU && u0 + lk < na;
+        const unsigned og0 = act0 ? ((unsigned)(rbase + lk) * SV_G + 16 * wave + ln) * 4u : SV_BUF_OOB;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                gi_nx[q][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gi_b, og0 + (g * SV_HP + 128 * q) * 4, 0, 0));
+    }
     for (int t = a.t0; t < a.t1; ++t) {
         if (na <= u0) break;
         SV_TS(0)
@@ -417,17 +427,26 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
         // 32-bit byte offsets of this lane's row (the host bounds B*Tmax so that they stay below 2^31)
         const bool act = lk < MU && u0 + lk < na;
         const unsigned row = rbase + lk;
-        const unsigned ogi = act ? (row * SV_G + 16 * wave + ln) * 4u : SV_BUF_OOB;
         const unsigned ohs = act ? (row * SV_HP + 16 * wave + ln) * 4u : SV_BUF_OOB;
         const unsigned og4 = act ? (row * SV_HP + 16 * wave + ln) * 16u : SV_BUF_OOB;
 
-        // input-side gates of this step: issued before the matmul so they land behind it
+        // Input-side gates: this step's were fetched one step ago; the NEXT step's are issued now, ahead of this
+        // step's stores.  VMEM operations retire in order, so a load issued behind the stores of the step before
+        // (as this step's own fetch used to be) cannot be waited for without waiting for those stores too.
         float gi[NQ][3];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                gi[q][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gi_b, ogi + (g * SV_HP + 128 * q) * 4, 0, 0));
+            for (int g = 0; g < 3; ++g) gi[q][g] = gi_nx[q][g];
+        {
+            const bool actn = lk < MU && u0 + lk < na_next && t + 1 < a.t1;
+            const unsigned ogn = actn ? ((unsigned)(rbase_next + lk) * SV_G + 16 * wave + ln) * 4u : SV_BUF_OOB;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    gi_nx[q][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gi_b, ogn + (g * SV_HP + 128 * q) * 4, 0, 0));
+        }
 
         bf16x8 A[KS];
 #pragma unroll
