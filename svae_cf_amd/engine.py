@@ -706,7 +706,9 @@ class SVAEEngine:
                 w3.wait_event(chain_done)
                 with _Launch(w3, self._torch_ctx()):
                     proj_dw(w["pslabs_side"])
-                    self._bucket(0)
+                    # (its bucket's all-reduce is issued by train_step AFTER the other buckets': collectives run in
+                    # issue order on RCCL's one stream, and this one, which waits for the sweep, would hold up the
+                    # embedding bucket that is ready a hundred microseconds earlier)
                 self._float_pending = True
             with _Launch(side, self._torch_ctx()):
                 if not floating:
@@ -840,10 +842,12 @@ class SVAEEngine:
         self.step_count += 1
         (s0, e0), rest = self.layout.buckets()[0], self.layout.buckets()[1:]
         cur = torch.cuda.current_stream()
+        w3 = self._side_stream(1, cur=cur)
         if gs is not None:
+            with _Launch(w3, True):
+                gs.bucket_ready(0)
             gs.wait(which=[i for i in range(1, 1 + len(rest))])
         self._adam_range(rest[0][0], rest[-1][1], gscale, cur.cuda_stream)
-        w3 = self._side_stream(1, cur=cur)
         with _Launch(w3, gs is not None):
             if gs is not None:
                 gs.wait(which=[0])
