@@ -99,39 +99,32 @@ def main():
         torch.cuda.synchronize()
 
     step = 0
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         eng.train_step(plans[step % len(plans)], 0.01, seed=1234)
         step += 1
-    # Kernel durations come from HIP events recorded on the launch stream around the kernel.  In the TIMED region
-    # only the dominant kernel (the projection sweep, two launches per step) is bracketed: bracketing all ~15
-    # kernel kinds costs ~0.4 ms of host time per step and makes the step host-bound (measured: 150k vs 205k
-    # seq/s).  The other kernels are bracketed in a short untimed pass afterwards ("kernel_ms_untimed_pass").
-    tags_timed = ["proj_fdh_fused", "proj_dw_fused"]
+    # The timed region carries NO events.  A HIP event recorded between queued kernels (or attached to a dispatch)
+    # stalls the asynchronous launch pipeline on this stack: 150-600 us of host time per record once kernels are in
+    # flight, and with the two sweeps bracketed on every 4th step some processes measured 130k seq/s where the
+    # unbracketed loop gives 256k (bimodal: the same command, run three times on one box, gave 249k / 136k / 130k).
+    # Kernel durations are therefore measured with HIP events on the launch streams in a REPLAY of the timed steps
+    # (same plans, same order, same process) right after the timed region; the sweeps use start / stop events attached
+    # to the dispatch itself (hipExtLaunchKernelGGL: the kernel's own timestamps, what rocprofv3 reports).
     tags_all = ["mlp_fwd", "mlp_bwd", "wgrad", "proj_fwd", "proj_fdh_fused", "proj_fdh_finish", "proj_dw_fused",
-                "proj_dw_finish", "proj_dw", "proj_dx", "softmax_nll", "gru_fwd", "gru_fwd2", "gru_bwd"]
-    if args.prec != "bf16":
-        tags_timed = ["proj_fwd", "proj_dw", "proj_dx", "softmax_nll"]
-    eng.prof = None if args.no_kernel_times else {t: [] for t in tags_timed}
-    if eng.prof is not None:
-        eng.event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * len(tags_timed) * args.steps + 8)]
+                "proj_dw_finish", "proj_dw", "proj_dx", "softmax_nll", "gru_fwd", "gru_fwd2", "gru_bwd", "gi_gemm",
+                "demb_gemm"]
+    eng.prof = None
     barrier()
     t0 = time.perf_counter()
     users_done = 0
     rows_done = 0
-    # HIP events around a kernel are not free on the GPU side either (each record is a barrier packet in the
-    # hardware queue: bracketing the two sweeps on every step cost 5-8 % of the step, 1.10 -> 1.17 ms), so the
-    # timed region brackets them on every 4th step; plans rotate with period 16, so every plan is sampled.
-    prof_timed, sample_every = eng.prof, 4
-    rows_bracketed, rows_extra = [], []
+    first_step = step
     for i in range(args.steps):
         p = plans[step % len(plans)]
-        eng.prof = prof_timed if (prof_timed is not None and i % sample_every == i // len(plans) % sample_every) else None
-        if eng.prof is not None:
-            rows_bracketed.append(p.R)
         eng.train_step(p, 0.01, seed=1234)
         users_done += p.B
         rows_done += p.R
         step += 1
+    t_enq = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     loss = float(eng.loss_out[0])
@@ -142,7 +135,6 @@ def main():
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
     dt, total_users = float(t[0]), float(u[0])
 
-    # per-kernel average durations: the dominant kernel over the timed region, the rest over 6 extra steps
     # (per STEP: a kernel launched twice in a step -- the forward sweep and the recurrence run in two time ranges --
     # counts with the sum of its launches)
     def harvest(nsteps):
@@ -153,17 +145,16 @@ def main():
         if "gru_fwd2" in out:
             out["gru_fwd"] = out.get("gru_fwd", 0.0) + out.pop("gru_fwd2")
         return out
-    eng.prof = prof_timed
-    kt = harvest(len(rows_bracketed))
-    kt_extra = {}
+    kt, replay_steps = {}, 0
     if not args.no_kernel_times:
+        replay_steps = min(args.steps, 48)
         eng.prof = {t: [] for t in tags_all}
-        for _ in range(6):
-            rows_extra.append(plans[step % len(plans)].R)
-            eng.train_step(plans[step % len(plans)], 0.01, seed=1234)
-            step += 1
+        for i in range(replay_steps):
+            eng.train_step(plans[(first_step + i) % len(plans)], 0.01, seed=1234)
         torch.cuda.synchronize()
-        kt_extra = {k: v for k, v in harvest(len(rows_extra)).items() if k not in kt}
+        kt = harvest(replay_steps)
+    rows_bracketed = [plans[(first_step + i) % len(plans)].R for i in range(replay_steps)]
+    rows_extra, kt_extra = [], {}
     eng.prof = None
     kt_all = dict(kt_extra)
     kt_all.update(kt)
@@ -195,7 +186,7 @@ def main():
         else:
             ach, peak, unit = amount / (ms * 1e-3) / 1e9, PEAK["hbm"], "GB/s"
         rooflines[tag] = dict(bound=bound, kernel=tag, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
-                              traffic=None, avg_ms=ms, timed_region=tag in kt)
+                              traffic=None, avg_ms=ms)
     # HBM bytes per launch from the PMC passes (tools/gpu_pmc.sh + tools/pmc_traffic.py: FETCH_SIZE doubled, the
     # gfx950 correction of MI355X_MICROARCH.md; separate --pmc runs), committed under profiles/.
     pmc = {}
@@ -236,13 +227,14 @@ def main():
         out = {
             "metric": "train sequences/sec (ML-20M shape)", "value": total_users / dt, "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "ML-20M-shaped synthetic (configs[2]): 20000 items, seq<=200, "
                                    "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam" % B,
                        "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "mean_rows_bracketed_steps": rows_timed, "parallelism": "dp%d" % world,
                        "final_loss": loss, "side_stream": eng.side_stream_info},
-            "kernel_ms": kt, "kernel_ms_untimed_pass": kt_extra, "roofline": roofline, "rooflines": rooflines,
+            "kernel_ms": kt, "kernel_timing": "HIP events on the launch streams over a replay of the first %d timed steps "
+                                             "(events inside the timed region stall the launch pipeline)" % replay_steps, "roofline": roofline, "rooflines": rooflines,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

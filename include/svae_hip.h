@@ -180,6 +180,14 @@ int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int
                          const int* occ_items, int nocc_long, float* slabs, float* gw3, float* gb3,
                          const int* sched, int nwg, int ns_q, int ns_rem, int parts, void* stream);
 
+/* Timing hooks (measurement only; no counterpart in the reference): svae_proj_time_next arms the calling thread's next
+ * sweep launch with start / stop events (from svae_event_create) attached to the dispatch itself; read the kernel's
+ * duration with svae_event_elapsed_ms (synchronises on the stop event). */
+int svae_event_create(void** out_event);
+int svae_event_destroy(void* event);
+int svae_event_elapsed_ms(void* start, void* stop, float* ms);
+int svae_proj_time_next(void* start, void* stop);
+
 /* ---- Adam with L2 weight decay on one flat buffer ----------------------------------------------------
  * Replaces optimizer.step() nb:1206 with torch.optim.Adam(weight_decay=5e-3) nb:1260-1263 (and the
  * zero_grad pair nb:1197-1198: gradients are written, not accumulated).  step is 1-based. */

@@ -52,6 +52,10 @@ SIGNATURES = {
     "svae_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "svae_mlp_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "svae_spin": [_I, _P],
+    "svae_event_create": [_P],
+    "svae_event_destroy": [_P],
+    "svae_event_elapsed_ms": [_P, _P, _P],
+    "svae_proj_time_next": [_P, _P],
     "svae_rowgemm_frag_elems": [_I],
     "svae_rowgemm_prep": [_P, _I, _P, _P],
     "svae_rowgemm": [_P, _P, _P, _P, _I, _I, _P],
@@ -122,6 +126,25 @@ def proj_schedule(nx, ny, ncu, uniform=False):
     if n <= 0:
         raise SvaeHipError("svae_proj_schedule failed (rc=%d): %s" % (n, lib.svae_last_error().decode("utf-8", "replace")))
     return buf[:n].copy(), q.value, rem.value
+
+
+class DispatchTimer:
+    """A start / stop event pair attached to ONE kernel dispatch (svae_proj_time_next); quacks like the
+    (start, stop) pairs of torch events the engine's profiling lists hold: ``pair[0].elapsed_time(pair[1])``."""
+
+    def __init__(self):
+        a, b = _c.c_void_p(), _c.c_void_p()
+        call("svae_event_create", _c.byref(a))
+        call("svae_event_create", _c.byref(b))
+        self.start, self.stop = a.value, b.value
+
+    def arm(self):
+        call("svae_proj_time_next", self.start, self.stop)
+
+    def elapsed_time(self, other=None):
+        ms = _c.c_float()
+        call("svae_event_elapsed_ms", self.start, self.stop, _c.byref(ms))
+        return float(ms.value)
 
 
 def ptr(t):

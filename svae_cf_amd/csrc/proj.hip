@@ -48,6 +48,8 @@
 // then stay in that XCD's L2.  Each split writes its own fp32 slab (deterministic; no atomics).
 #include <algorithm>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 #ifdef SV_PROJ_TIMING   // diagnostic build only (tools/proj_timing.py): phase stamps of waves 0 and 4 of block 0
@@ -707,6 +709,12 @@ __global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __rest
     dw_write_row(s, wsum, it, lane, gw3, gb3);
 }
 
+// Optional timing of the NEXT sweep launch of this thread: the start / stop events are attached to the dispatch itself
+// (hipExtLaunchKernelGGL), so they take the kernel's own begin and end timestamps and put no marker packets into the
+// queue.  (Bracketing a launch with hipEventRecord cost the host 150 us per record once kernels were in flight --
+// 600 us in the first GPU process of a freshly booted box -- which made a bracketed step host-bound.)
+thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+
 template <int MODE>
 int launch_proj(ProjArgs a, int nwg, hipStream_t st) {
     static bool attr_done = false;
@@ -715,7 +723,12 @@ int launch_proj(ProjArgs a, int nwg, hipStream_t st) {
         if (e != hipSuccess) return svae_fail((int)e, "svae_proj: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((proj_kernel<MODE>), dim3(nwg), dim3(512), LDS_BYTES, st, a);
+    if (g_time_start != nullptr && g_time_stop != nullptr) {
+        hipExtLaunchKernelGGL((proj_kernel<MODE>), dim3(nwg), dim3(512), LDS_BYTES, st, g_time_start, g_time_stop, 0, a);
+        g_time_start = g_time_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL((proj_kernel<MODE>), dim3(nwg), dim3(512), LDS_BYTES, st, a);
+    }
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -731,6 +744,35 @@ extern "C" int svae_debug_proj_blocks(unsigned long long* out) {
 }
 #endif
 extern "C" int svae_proj_nsplit(void) { return NSPLIT; }
+
+// Timing hooks (measurement only; no counterpart in the reference).  svae_proj_time_next arms the calling thread's next
+// sweep launch (svae_proj_nll_fwd / _fwd_dh / _bwd_dw, part 1) with a start and a stop event created by
+// svae_event_create; svae_event_elapsed_ms reads the kernel's duration once it has finished.
+extern "C" int svae_event_create(void** out) {
+    if (!out) return svae_fail(-1, "svae_event_create: null pointer");
+    hipEvent_t e = nullptr;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return svae_fail((int)rc, "svae_event_create: %s", hipGetErrorString(rc));
+    *out = (void*)e;
+    return 0;
+}
+extern "C" int svae_event_destroy(void* e) {
+    hipError_t rc = hipEventDestroy((hipEvent_t)e);
+    if (rc != hipSuccess) return svae_fail((int)rc, "svae_event_destroy: %s", hipGetErrorString(rc));
+    return 0;
+}
+extern "C" int svae_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (!start || !stop || !ms) return svae_fail(-1, "svae_event_elapsed_ms: null pointer");
+    hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+    if (rc == hipSuccess) rc = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    if (rc != hipSuccess) return svae_fail((int)rc, "svae_event_elapsed_ms: %s", hipGetErrorString(rc));
+    return 0;
+}
+extern "C" int svae_proj_time_next(void* start, void* stop) {
+    g_time_start = (hipEvent_t)start;
+    g_time_stop = (hipEvent_t)stop;
+    return 0;
+}
 extern "C" int svae_proj_ns_max(void) { return NS_MAX; }
 
 // Work division of one projection sweep (HOST function, no GPU work): nx resident rows in x tiles of 256, ny
