@@ -194,6 +194,16 @@ int svae_proj_time_next(void* start, void* stop);
 int svae_adam_step(float* p, const float* g, float* m, float* v, long long n, int step, float lr, float b1, float b2,
                    float eps, float wd, float gscale, void* stream);
 
+/* ---- the notebook's other optimizers on one flat buffer ---------------------------------------------
+ * Replaces optimizer.step() nb:1206 for hyper_params['optimizer'] in {adagrad, adadelta, rmsprop}
+ * (nb:1252-1259, nb:1264-1267), torch.optim semantics with L2 decay added to the gradient first:
+ * kind 0 Adagrad  (a = state_sum, decay = lr_decay, eps 1e-10 by default), kind 1 Adadelta (a = square_avg,
+ * b = acc_delta, decay = rho), kind 2 RMSprop (a = square_avg, decay = alpha; plain: no momentum, not
+ * centered).  b may be NULL unless kind == 1; step is 1-based (Adagrad's lr decay).
+ * decay is a double: 1 - decay is rounded from the double difference, as torch does. */
+int svae_optimizer_step(int kind, float* p, const float* g, float* a, float* b, long long n, int step, float lr,
+                        double decay, float eps, float wd, float gscale, void* stream);
+
 /* ---- scoring ------------------------------------------------------------------------------------------
  * svae_masked_topk replaces the seen-item mask nb:621-624 and torch.sort(-scores)[:k] nb:632-636:
  * score_i = s_i - |s_i * m_i| * 1e8, descending, ties by lower index.  seen / seen_off: CSR of each

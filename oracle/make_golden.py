@@ -174,17 +174,32 @@ def case_train(ns_factory, name, total_items, n_users, next_k, seed):
     print("wrote", name, "losses", losses[:3], "...", losses[-1])
 
 
-def case_batch_adam(ns_factory, name, total_items, lens_per_step, next_k, seed):
+def make_optimizer(kind, model, hp):
+    """The notebook's optimizer selection, nb:1252-1267 (same constructor calls)."""
+    if kind == "adagrad":
+        return torch.optim.Adagrad(model.parameters(), weight_decay=hp["weight_decay"], lr=hp["learning_rate"])
+    if kind == "adadelta":
+        return torch.optim.Adadelta(model.parameters(), weight_decay=hp["weight_decay"])
+    if kind == "rmsprop":
+        return torch.optim.RMSprop(model.parameters(), weight_decay=hp["weight_decay"])
+    return torch.optim.Adam(model.parameters(), weight_decay=hp["weight_decay"])
+
+
+def case_batch_adam(ns_factory, name, total_items, lens_per_step, next_k, seed, kind="adam", slim=False,
+                    probe_lens=None):
     """Batched contract: loss = mean over users of the reference single-user VAELoss;
-    torch autograd + torch.optim.Adam(weight_decay=5e-3) for len(lens_per_step) steps."""
+    torch autograd + the notebook's optimizer of that kind (nb:1252-1267) for len(lens_per_step) steps.
+    slim: no first-step gradients in the file (the Adam case holds them).
+    probe_lens: after the last step, the loss (no step) of one more batch at the new parameters."""
     hp = hp_default(total_items, next_k)
+    hp["learning_rate"] = 0.01            # nb:75 (used by adagrad only)
     ns = ns_factory(hp)
     rs = np.random.RandomState(seed)
     model = ns["Model"](hp)
     load_params(model, O.make_params(total_items, seed))
     crit = ns["VAELoss"](hp)
-    opt = torch.optim.Adam(model.parameters(), weight_decay=hp["weight_decay"])
-    out = dict(total_items=total_items, next_k=next_k, seed=seed, n_steps=len(lens_per_step))
+    opt = make_optimizer(kind, model, hp)
+    out = dict(total_items=total_items, next_k=next_k, seed=seed, n_steps=len(lens_per_step), optimizer=kind)
     losses = []
     for s, lens in enumerate(lens_per_step):
         users = [rs.permutation(total_items)[:n].astype(np.int64) for n in lens]
@@ -203,7 +218,7 @@ def case_batch_adam(ns_factory, name, total_items, lens_per_step, next_k, seed):
             out["s%d_u%d_items" % (s, j)] = items
             out["s%d_u%d_eps" % (s, j)] = eps
         tot.backward()
-        if s == 0:
+        if s == 0 and not slim:
             for k, v in model.named_parameters():
                 out["s0_grad/" + k] = v.grad.detach().numpy().copy()
         opt.step()
@@ -213,8 +228,50 @@ def case_batch_adam(ns_factory, name, total_items, lens_per_step, next_k, seed):
     out["losses"] = np.array(losses)
     for k, v in model.state_dict().items():
         out["final/" + k] = v.numpy().copy()
+    if probe_lens:
+        users = [rs.permutation(total_items)[:n].astype(np.int64) for n in probe_lens]
+        tot = 0.0
+        for j, items in enumerate(users):
+            x, tgt = O.build_inputs_targets(items, next_k)
+            y = torch.from_numpy(O.dense_targets(tgt, total_items))[None]
+            sd = seed + 77000 + j
+            np.random.seed(sd)
+            eps = np.random.normal(0, 1, size=(len(x), 64)).astype(np.float32)
+            np.random.seed(sd)
+            with torch.no_grad():
+                dec, mu, ls = model(torch.from_numpy(x)[None])
+                tot = tot + crit(dec, mu, ls, y, 0.2) / float(len(users))
+            out["probe_u%d_items" % j] = items
+            out["probe_u%d_eps" % j] = eps
+        out["probe_n_users"] = len(users)
+        out["probe_loss"] = np.float64(float(tot))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("wrote", name, "losses", losses)
+
+
+def case_optimizer_steps(name, n, n_steps, seed):
+    """The optimizers alone, constructed as nb:1252-1267 constructs them (torch.optim is where their arithmetic
+    lives): one flat parameter of n elements, n_steps given gradients, the parameter after every step."""
+    rs = np.random.RandomState(seed)
+    p0 = (rs.standard_normal(n) * 0.3).astype(np.float32)
+    p0[:16] = 0.0                                      # rows that never see a gradient (pads, unseen items)
+    grads = (rs.standard_normal((n_steps, n)) * np.exp(rs.uniform(-12, 2, size=n))[None]).astype(np.float32)
+    grads[:, :16] = 0.0
+    hp = {"weight_decay": float(5e-3), "learning_rate": 0.01}
+    out = dict(p0=p0, grads=grads, n_steps=n_steps)
+    for kind in ("adam", "adagrad", "adadelta", "rmsprop"):
+        par = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+        holder = torch.nn.ParameterList([par])
+        opt = make_optimizer(kind, holder, hp)
+        traj = []
+        for s in range(n_steps):
+            opt.zero_grad()
+            par.grad = torch.from_numpy(grads[s].copy())
+            opt.step()
+            traj.append(par.detach().numpy().copy())
+        out[kind] = np.stack(traj)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
 
 
 def case_eval(ns_factory, name, total_items, n_users, next_k, seed, is_train_set):
@@ -292,6 +349,16 @@ def main():
     case_forward_backward(factory, "fwd_bwd_I64_postfix", 64, [7, 6], 4, 13, 0.1, loss_type="postfix")
     case_train(factory, "train_I97", 97, 12, 4, 21)
     case_batch_adam(factory, "batch_adam_I97", 97, [[9, 17, 5], [30, 6, 6, 12], [4, 8]], 4, 31)
+    for kind in ("adagrad", "adadelta"):
+        case_batch_adam(factory, "batch_%s_I53" % kind, 53, [[9, 17, 5], [12, 6, 6], [4, 8], [21, 7, 3]], 4, 33,
+                        kind=kind, slim=True)
+    # RMSprop at torch's default lr 0.01 moves EVERY weight by 0.1 in its first step (g / sqrt(0.01 g^2)); the model
+    # is then in a saturated, ill-conditioned state (the reference's own loss goes 39 -> 38 -> 19 931), where two
+    # fp32 implementations of the same gradient differ by 1 %.  The end-to-end case is therefore ONE step plus the
+    # loss of a probe batch at the new parameters; the multi-step arithmetic is pinned by case_optimizer_steps.
+    case_batch_adam(factory, "batch_rmsprop_I53", 53, [[9, 17, 5]], 4, 33, kind="rmsprop", slim=True,
+                    probe_lens=[12, 6, 6])
+    case_optimizer_steps("optimizer_steps", 4096, 6, 51)
     case_eval(factory, "eval_val_I211", 211, 6, 4, 41, False)
     case_eval(factory, "eval_train_I211", 211, 7, 4, 42, True)
 

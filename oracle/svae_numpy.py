@@ -284,6 +284,51 @@ def adam_step(p, grads, st, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weight_decay=5e
     return p
 
 
+# --------------------------------------------------------------------------
+# the notebook's other optimizers (nb:1252-1259, nb:1264-1267): torch.optim.Adagrad(lr=hyper_params
+# ['learning_rate'], weight_decay), Adadelta(weight_decay), RMSprop(weight_decay) -- torch's defaults
+# otherwise (Adagrad lr_decay 0, eps 1e-10; Adadelta lr 1.0, rho 0.9, eps 1e-6; RMSprop lr 0.01,
+# alpha 0.99, eps 1e-8, no momentum, not centered).  All add L2 decay to the gradient first.
+# --------------------------------------------------------------------------
+def opt_init(p):
+    return dict(step=0, a={k: np.zeros_like(v) for k, v in p.items()},
+                b={k: np.zeros_like(v) for k, v in p.items()})
+
+
+def adagrad_step(p, grads, st, lr=1e-2, lr_decay=0.0, eps=1e-10, weight_decay=5e-3):
+    st["step"] += 1
+    clr = lr / (1.0 + (st["step"] - 1) * lr_decay)
+    for k in p:
+        dt = p[k].dtype.type
+        g = grads[k] + dt(weight_decay) * p[k]
+        st["a"][k] = st["a"][k] + g * g                       # state_sum
+        p[k] = p[k] - dt(clr) * (g / (np.sqrt(st["a"][k]) + dt(eps)))
+    return p
+
+
+def adadelta_step(p, grads, st, lr=1.0, rho=0.9, eps=1e-6, weight_decay=5e-3):
+    st["step"] += 1
+    for k in p:
+        dt = p[k].dtype.type
+        g = grads[k] + dt(weight_decay) * p[k]
+        st["a"][k] = dt(rho) * st["a"][k] + dt(1.0 - rho) * g * g          # square_avg
+        std = np.sqrt(st["a"][k] + dt(eps))
+        delta = np.sqrt(st["b"][k] + dt(eps)) / std * g
+        st["b"][k] = dt(rho) * st["b"][k] + dt(1.0 - rho) * delta * delta  # acc_delta
+        p[k] = p[k] - dt(lr) * delta
+    return p
+
+
+def rmsprop_step(p, grads, st, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=5e-3):
+    st["step"] += 1
+    for k in p:
+        dt = p[k].dtype.type
+        g = grads[k] + dt(weight_decay) * p[k]
+        st["a"][k] = dt(alpha) * st["a"][k] + dt(1.0 - alpha) * g * g      # square_avg
+        p[k] = p[k] - dt(lr) * (g / (np.sqrt(st["a"][k]) + dt(eps)))
+    return p
+
+
 def anneal_for_batch(b, total_anneal_steps=200000, cap=0.2):
     """Anneal used by the b-th step (1-based) of an epoch (nb:1188-1191, nb:1211-1215).
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     "svae_latent_bwd": [_P, _P, _P, _P, _F, _P, _I, _P],
     "svae_softmax_nll": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "svae_adam_step": [_P, _P, _P, _P, _LL, _I, _F, _F, _F, _F, _F, _F, _P],
+    "svae_optimizer_step": [_I, _P, _P, _P, _P, _LL, _I, _F, _c.c_double, _F, _F, _F, _P],
     "svae_colsum": [_P, _P, _P, _I, _I, _I, _I, _P],
     "svae_transpose": [_P, _P, _I, _I, _P],
     "svae_loss_reduce": [_P, _P, _P, _P, _F, _I, _P, _P],

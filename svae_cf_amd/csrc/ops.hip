@@ -221,6 +221,52 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The notebook's other optimizers (nb:1252-1259, nb:1264-1267) on one flat buffer, torch.optim semantics:
+// KIND 0 Adagrad   a = state_sum;                 p -= clr * g / (sqrt(a) + eps)
+// KIND 1 Adadelta  a = square_avg, b = acc_delta; p -= lr * sqrt(b + eps) / sqrt(a + eps) * g
+// KIND 2 RMSprop   a = square_avg;                p -= lr * g / (sqrt(a) + eps)      (no momentum, not centered)
+// g = gscale * grad + wd * p; omd = 1 - decay, rounded from the DOUBLE difference as torch does (1.0f - 0.99f is
+// 9.3e-7 away from 0.01f, which RMSprop's g / sqrt(a) shows after three steps).  HBM-bound: 16 B read + 8..12 B written per element.
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void opt_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ a,
+                           float* __restrict__ b, long long n4, float lr, float decay, float omd, float eps,
+                           float wd, float gscale) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        float4 A = reinterpret_cast<float4*>(a)[i];
+        float4 Bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KIND == 1) Bv = reinterpret_cast<float4*>(b)[i];
+        float* pp = reinterpret_cast<float*>(&P);
+        const float* gg = reinterpret_cast<const float*>(&G);
+        float* aa = reinterpret_cast<float*>(&A);
+        float* bb = reinterpret_cast<float*>(&Bv);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gr = gg[c] * gscale + wd * pp[c];
+            if (KIND == 0) {
+                aa[c] = aa[c] + gr * gr;
+                pp[c] = pp[c] - lr * (gr / (sqrtf(aa[c]) + eps));
+            } else if (KIND == 1) {
+                aa[c] = aa[c] * decay + gr * gr * omd;
+                const float delta = sqrtf(bb[c] + eps) / sqrtf(aa[c] + eps) * gr;
+                bb[c] = bb[c] * decay + delta * delta * omd;
+                pp[c] = pp[c] - lr * delta;
+            } else {
+                aa[c] = aa[c] * decay + gr * gr * omd;
+                pp[c] = pp[c] - lr * (gr / (sqrtf(aa[c]) + eps));
+            }
+        }
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(a)[i] = A;
+        if (KIND == 1) reinterpret_cast<float4*>(b)[i] = Bv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // column sums of a [R][ld] matrix (bias gradients), deterministic two-stage
 // ------------------------------------------------------------------------------------------------
 __global__ void colsum_partial_kernel(const float* __restrict__ a, float* __restrict__ part, int R, int N, int ld,
@@ -629,6 +675,33 @@ extern "C" int svae_adam_step(float* p, const float* g, float* m, float* v, long
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, b1, b2, step_size,
                        inv_sqrt_bc2, eps, wd, gscale);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// Reference interface replaced: optimizer.step() with the notebook's other optimizer choices (nb:1252-1259,
+// nb:1264-1267).  kind 0 = torch.optim.Adagrad (a = state_sum; decay = lr_decay; step 1-based), 1 = Adadelta
+// (a = square_avg, b = acc_delta; decay = rho), 2 = RMSprop (a = square_avg; decay = alpha; plain: no momentum,
+// not centered).  b may be NULL unless kind == 1.
+extern "C" int svae_optimizer_step(int kind, float* p, const float* g, float* a, float* b, long long n, int step,
+                                   float lr, double decay, float eps, float wd, float gscale, void* stream) {
+    SV_CHECK_ARG(kind >= 0 && kind <= 2, "svae_optimizer_step: kind must be 0 (adagrad), 1 (adadelta) or 2 (rmsprop)");
+    SV_CHECK_ARG(p && g && a && (kind != 1 || b) && n > 0 && (n % 4) == 0 && step >= 1,
+                 "svae_optimizer_step: bad arguments");
+    long long n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    const float d = (float)decay, omd = (float)(1.0 - decay);
+    if (kind == 0) {
+        const float clr = (float)((double)lr / (1.0 + (double)(step - 1) * decay));
+        hipLaunchKernelGGL(opt_kernel<0>, dim3(blocks), dim3(256), 0, st, p, g, a, b, n4, clr, 0.0f, 0.0f, eps, wd,
+                           gscale);
+    } else if (kind == 1) {
+        hipLaunchKernelGGL(opt_kernel<1>, dim3(blocks), dim3(256), 0, st, p, g, a, b, n4, lr, d, omd, eps, wd, gscale);
+    } else {
+        hipLaunchKernelGGL(opt_kernel<2>, dim3(blocks), dim3(256), 0, st, p, g, a, b, n4, lr, d, omd, eps, wd, gscale);
+    }
     SV_LAUNCH_CHECK();
     return 0;
 }

@@ -76,6 +76,10 @@ class SVAEEngine:
         self.exp_avg = torch.zeros(n, **f32)
         self.exp_avg_sq = torch.zeros(n, **f32)
         self.step_count = 0
+        # which optimizer optimizer.step() runs (nb:1252-1267): "adam" (the default the reference trains with), or
+        # (kind, decay, eps) of svae_optimizer_step for adagrad / adadelta / rmsprop -- set by set_optimizer()
+        self.optimizer = "adam"
+        self._opt = None
         self._pviews, self._gviews = {}, {}
         self._gbase = self.grads.data_ptr()
         self.whh_t = torch.zeros(HP * G, **f32)
@@ -823,7 +827,28 @@ class SVAEEngine:
         self.step_count += 1
         self._adam_range(0, self.layout.total, gscale, _stream())
 
+    OPTIMIZERS = {"adam": None, "adagrad": 0, "adadelta": 1, "rmsprop": 2}
+
+    def set_optimizer(self, kind, lr, weight_decay, decay=0.0, eps=1e-8, betas=(0.9, 0.999)):
+        """Selects what optimizer.step() runs (nb:1252-1267) and clears its state.  decay = Adagrad's lr_decay,
+        Adadelta's rho, RMSprop's alpha; exp_avg_sq holds state_sum / square_avg, exp_avg holds acc_delta."""
+        if kind not in self.OPTIMIZERS:
+            raise ValueError("unknown optimizer %r (the notebook knows adagrad, adadelta, adam, rmsprop)" % (kind,))
+        self.reset_optimizer()
+        self.optimizer, self.lr, self.weight_decay = kind, float(lr), float(weight_decay)
+        if kind == "adam":
+            self.betas, self.adam_eps, self._opt = betas, float(eps), None
+        else:
+            self._opt = (self.OPTIMIZERS[kind], float(decay), float(eps))
+
     def _adam_range(self, s, e, gscale, st):
+        """The optimizer over elements [s, e) of the flat buffers (Adam unless set_optimizer chose another)."""
+        if self._opt is not None:
+            kind, decay, eps = self._opt
+            _lib.call("svae_optimizer_step", kind, self.params.data_ptr() + 4 * s, self.grads.data_ptr() + 4 * s,
+                      self.exp_avg_sq.data_ptr() + 4 * s, self.exp_avg.data_ptr() + 4 * s, e - s, self.step_count,
+                      self.lr, decay, eps, self.weight_decay, float(gscale), st)
+            return
         _lib.call("svae_adam_step", self.params.data_ptr() + 4 * s, self.grads.data_ptr() + 4 * s,
                   self.exp_avg.data_ptr() + 4 * s, self.exp_avg_sq.data_ptr() + 4 * s, e - s, self.step_count, self.lr,
                   self.betas[0], self.betas[1], self.adam_eps, self.weight_decay, float(gscale), st)

@@ -202,13 +202,73 @@ class Adam:
         if not isinstance(self.model, Model):
             raise TypeError("pass the Model: Adam(model, weight_decay=...)")
         e = self.model.engine
-        e.lr, e.betas, e.adam_eps, e.weight_decay = lr, betas, eps, weight_decay
+        e.set_optimizer("adam", lr, weight_decay, eps=eps, betas=betas)
 
     def zero_grad(self):
         pass        # gradients are written, never accumulated (nb:1197-1198 become no-ops)
 
     def step(self):
         self.model.engine.adam_step()
+
+
+class _EngineOptimizer:
+    """Shared shape of the look-alikes below: construction selects the engine's optimizer kernel and clears its state,
+    zero_grad is a no-op (gradients are written, never accumulated), step runs one fused launch over the flat buffers."""
+
+    def __init__(self, model):
+        if not isinstance(model, Model):
+            raise TypeError("pass the Model: %s(model, weight_decay=...)" % type(self).__name__)
+        self.model = model
+
+    def zero_grad(self):
+        pass
+
+    def step(self):
+        self.model.engine.adam_step()
+
+
+class Adagrad(_EngineOptimizer):
+    """torch.optim.Adagrad(model.parameters(), weight_decay=wd, lr=hyper_params['learning_rate']) look-alike
+    (nb:1252-1255); torch's defaults otherwise (initial_accumulator_value 0)."""
+
+    def __init__(self, model, lr=1e-2, lr_decay=0.0, weight_decay=0.0, eps=1e-10):
+        super().__init__(model)
+        model.engine.set_optimizer("adagrad", lr, weight_decay, decay=lr_decay, eps=eps)
+
+
+class Adadelta(_EngineOptimizer):
+    """torch.optim.Adadelta(model.parameters(), weight_decay=wd) look-alike (nb:1256-1259)."""
+
+    def __init__(self, model, lr=1.0, rho=0.9, eps=1e-6, weight_decay=0.0):
+        super().__init__(model)
+        model.engine.set_optimizer("adadelta", lr, weight_decay, decay=rho, eps=eps)
+
+
+class RMSprop(_EngineOptimizer):
+    """torch.optim.RMSprop(model.parameters(), weight_decay=wd) look-alike (nb:1264-1267): plain RMSprop, as the
+    notebook constructs it (momentum and centered, which it never sets, are refused)."""
+
+    def __init__(self, model, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0, centered=False):
+        super().__init__(model)
+        if momentum or centered:
+            raise NotImplementedError("RMSprop with momentum / centered: the reference never asks for them")
+        model.engine.set_optimizer("rmsprop", lr, weight_decay, decay=alpha, eps=eps)
+
+
+def make_optimizer(model, hyper_params):
+    """The notebook's optimizer selection nb:1252-1267: hyper_params['optimizer'] in adagrad / adadelta / adam /
+    rmsprop; 'learning_rate' is read for adagrad only (nb:75), everything else runs at torch's defaults."""
+    kind, wd = hyper_params.get("optimizer", "adam"), hyper_params["weight_decay"]
+    if kind == "adagrad":
+        return Adagrad(model, weight_decay=wd, lr=hyper_params["learning_rate"])
+    if kind == "adadelta":
+        return Adadelta(model, weight_decay=wd)
+    if kind == "adam":
+        return Adam(model, weight_decay=wd)
+    if kind == "rmsprop":
+        return RMSprop(model, weight_decay=wd)
+    raise ValueError("hyper_params['optimizer'] = %r: the notebook defines adagrad, adadelta, adam, rmsprop "
+                     "(any other value leaves its `optimizer` undefined, nb:1252-1267)" % (kind,))
 
 
 # --------------------------------------------------------------------------------------------
@@ -458,8 +518,8 @@ def fit(model, criterion, train_reader, val_reader, test_reader, hyper_params, o
     ``checkpoint_path`` with torch.save when given) instead of a pickled module (nb:1304); ``batch_size`` switches
     the per-epoch training from the notebook's per-user ``train`` to ``train_batched``.
     Returns (test metrics, len_to_ndcg_at_100_map, best validation NDCG@100)."""
-    if optimizer is None and batch_size is None:
-        optimizer = Adam(model, weight_decay=hyper_params["weight_decay"])
+    if optimizer is None:             # nb:1252-1267; it also configures the engine's step for train_batched
+        optimizer = make_optimizer(model, hyper_params)
     best_val_ndcg, best_state = None, None
     for epoch in range(1, hyper_params["epochs"] + 1):
         epoch_start_time = time.time()

@@ -45,8 +45,8 @@ def _param_gate(got, ref, name, tol=1e-4):
     d = np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64)
     l2 = np.linalg.norm(d) / np.linalg.norm(ref)
     assert l2 <= tol, (name, l2)
-    frac = float((np.abs(d) > tol * np.abs(ref).max()).mean())
-    assert frac <= 1e-4, (name, frac)
+    nout = int((np.abs(d) > tol * np.abs(ref).max()).sum())      # (one element is allowed in a tensor under 10^4)
+    assert nout <= max(1, int(1e-4 * d.size)), (name, nout, d.size)
 
 
 def _kk(g):
@@ -130,6 +130,81 @@ def test_batched_steps_vs_reference(golden_dir):
     sd = eng.state_dict()
     for k in O.PARAM_NAMES:
         _param_gate(sd[k].cpu().numpy(), g["final/" + k], k)
+
+
+@pytest.mark.parametrize("kind", ["adam", "adagrad", "adadelta", "rmsprop"])
+def test_optimizer_kernels_vs_torch_optim(golden_dir, kind):
+    """svae_adam_step / svae_optimizer_step through the C-ABI on given gradients against torch.optim's trajectory
+    (fixture optimizer_steps, constructed as nb:1252-1267): every step to 4 ulp of the largest element."""
+    from svae_cf_amd import _lib
+    g = _load(golden_dir, "optimizer_steps")
+    dev = torch.device("cuda")
+    p = torch.from_numpy(g["p0"].copy()).to(dev)
+    a, b = torch.zeros_like(p), torch.zeros_like(p)
+    st = torch.cuda.current_stream().cuda_stream
+    hp = {"adagrad": (0, 1e-2, 0.0, 1e-10), "adadelta": (1, 1.0, 0.9, 1e-6), "rmsprop": (2, 1e-2, 0.99, 1e-8)}
+    for s in range(int(g["n_steps"])):
+        gr = torch.from_numpy(g["grads"][s].copy()).to(dev)
+        if kind == "adam":
+            _lib.call("svae_adam_step", p.data_ptr(), gr.data_ptr(), b.data_ptr(), a.data_ptr(), p.numel(), s + 1,
+                      1e-3, 0.9, 0.999, 1e-8, 5e-3, 1.0, st)
+        else:
+            k, lr, decay, eps = hp[kind]
+            _lib.call("svae_optimizer_step", k, p.data_ptr(), gr.data_ptr(), a.data_ptr(), b.data_ptr(), p.numel(),
+                      s + 1, lr, decay, eps, 5e-3, 1.0, st)
+        torch.cuda.synchronize()
+        ref = g[kind][s]
+        got = p.cpu().numpy()
+        assert np.abs(got.astype(np.float64) - ref).max() <= 5e-7 * np.abs(ref).max(), (kind, s)
+        np.testing.assert_array_equal(got[:16], 0.0)
+
+
+@pytest.mark.parametrize("kind", ["adagrad", "adadelta", "rmsprop"])
+def test_batched_steps_other_optimizers_vs_reference(golden_dir, kind):
+    """Ragged batches under the notebook's other optimizer choices (nb:1252-1259, nb:1264-1267) through the notebook
+    surface's make_optimizer; same gates as the Adam case (loss 1e-4, parameters rel-L2 1e-4; RMSprop 1e-3).  RMSprop: one step,
+    then the loss of a probe batch at the new parameters within the north-star 1e-3."""
+    import svae_cf_amd as S
+    from svae_cf_amd import notebook_api as N
+    g = _load(golden_dir, "batch_%s_I53" % kind)
+    I, seed = int(g["total_items"]), int(g["seed"])
+    hp = dict(item_embed_size=256, rnn_size=200, hidden_size=150, latent_size=64, total_items=I, batch_size=1,
+              weight_decay=5e-3, learning_rate=0.01, optimizer=kind)
+    model = N.Model(hp)
+    eng = model.engine
+    eng.load_state_dict(_sd(O.make_params(I, seed)))
+    opt = N.make_optimizer(model, hp)
+    losses = []
+    for s in range(int(g["n_steps"])):
+        nu = int(g["s%d_n_users" % s])
+        users = [g["s%d_u%d_items" % (s, j)] for j in range(nu)]
+        epsl = [g["s%d_u%d_eps" % (s, j)] for j in range(nu)]
+        plan = S.build_plan(users, 4, device="cuda")
+        eps = torch.from_numpy(S.pack_rows(plan, epsl, 64)).cuda()
+        eng.forward(plan, float(g["s%d_anneal" % s]), eps=eps)
+        eng.backward()
+        opt.step()
+        losses.append(float(eng.loss_out[0]))
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-4)
+    sd = eng.state_dict()
+    # (RMSprop: 1e-3, see tests/test_oracle_golden.py::test_other_optimizers_match_reference)
+    for k in O.PARAM_NAMES:
+        _param_gate(sd[k].cpu().numpy(), g["final/" + k], k, tol=1e-3 if kind == "rmsprop" else 1e-4)
+    if "probe_loss" in g.files:
+        nu = int(g["probe_n_users"])
+        plan = S.build_plan([g["probe_u%d_items" % j] for j in range(nu)], 4, device="cuda")
+        eps = torch.from_numpy(S.pack_rows(plan, [g["probe_u%d_eps" % j] for j in range(nu)], 64)).cuda()
+        out = eng.forward(plan, 0.2, eps=eps, want_grad=False)
+        ref = float(g["probe_loss"])
+        assert abs(float(out[0]) - ref) <= 1e-3 * abs(ref)
+
+
+def test_unknown_optimizer_is_refused():
+    from svae_cf_amd import notebook_api as N
+    hp = dict(item_embed_size=256, rnn_size=200, hidden_size=150, latent_size=64, total_items=40, batch_size=1,
+              weight_decay=5e-3, optimizer="sgd")
+    with pytest.raises(ValueError):
+        N.make_optimizer(N.Model(hp), hp)
 
 
 def test_larger_batch_vs_oracle():

@@ -39,8 +39,8 @@ def _param_gate(got, ref, name, tol=1e-4):
     d = got - ref
     l2 = np.linalg.norm(d) / np.linalg.norm(ref)
     assert l2 <= tol, (name, l2)
-    frac = float((np.abs(d) > tol * np.abs(ref).max()).mean())
-    assert frac <= 1e-4, (name, frac)
+    nout = int((np.abs(d) > tol * np.abs(ref).max()).sum())      # (one element is allowed in a tensor under 10^4)
+    assert nout <= max(1, int(1e-4 * d.size)), (name, nout, d.size)
 
 
 @pytest.mark.parametrize("name", FWD_CASES)
@@ -119,6 +119,53 @@ def test_batched_contract_matches_reference(golden_dir):
     np.testing.assert_allclose(losses, g["losses"], rtol=1e-4)
     for k in O.PARAM_NAMES:
         _param_gate(p[k], g["final/" + k], k)
+
+
+@pytest.mark.parametrize("kind", ["adam", "adagrad", "adadelta", "rmsprop"])
+def test_optimizer_arithmetic_matches_torch_optim(golden_dir, kind):
+    """The optimizers alone, as nb:1252-1267 constructs them, on given gradients (fixture made by torch.optim):
+    the parameter after every one of 6 steps, to 2 ulp of the largest element (fp32 arithmetic on both sides)."""
+    g = _load(golden_dir, "optimizer_steps")
+    p = {"w": g["p0"].copy()}
+    st = O.adam_init(p) if kind == "adam" else O.opt_init(p)
+    step = getattr(O, kind + "_step")
+    for s in range(int(g["n_steps"])):
+        p = step(p, {"w": g["grads"][s]}, st)
+        ref = g[kind][s]
+        assert np.abs(p["w"].astype(np.float64) - ref).max() <= 2.5e-7 * np.abs(ref).max(), (kind, s)
+        np.testing.assert_array_equal(p["w"][:16], 0.0)        # no gradient, no weight: stays exactly zero
+
+
+@pytest.mark.parametrize("kind", ["adagrad", "adadelta", "rmsprop"])
+def test_other_optimizers_match_reference(golden_dir, kind):
+    """Batched steps under the notebook's other optimizer choices (nb:1252-1259, nb:1264-1267).  RMSprop's case is
+    one step plus the loss of a probe batch at the new parameters (see oracle/make_golden.py for why)."""
+    g = _load(golden_dir, "batch_%s_I53" % kind)
+    assert str(g["optimizer"]) == kind
+    I, seed = int(g["total_items"]), int(g["seed"])
+    p = O.make_params(I, seed)
+    st = O.opt_init(p)
+    step = getattr(O, kind + "_step")
+    losses = []
+    for s in range(int(g["n_steps"])):
+        nu = int(g["s%d_n_users" % s])
+        users = [g["s%d_u%d_items" % (s, j)] for j in range(nu)]
+        eps = [g["s%d_u%d_eps" % (s, j)] for j in range(nu)]
+        loss, grads = O.batch_loss_and_grads(p, users, eps, float(g["s%d_anneal" % s]), 4, np.float32)
+        losses.append(loss)
+        p = step(p, grads, st)
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-4)
+    # RMSprop's first step is 10 lr g / (|g| + 1e-7): elements with |g| ~ 1e-7 (where fp32 summation order decides
+    # the second digit of g) move by anything up to lr * 10, so its gate is 1e-3; the arithmetic itself is pinned to
+    # 2 ulp by test_optimizer_arithmetic_matches_torch_optim
+    for k in O.PARAM_NAMES:
+        _param_gate(p[k], g["final/" + k], k, tol=1e-3 if kind == "rmsprop" else 1e-4)
+    if "probe_loss" in g.files:
+        nu = int(g["probe_n_users"])
+        users = [g["probe_u%d_items" % j] for j in range(nu)]
+        eps = [g["probe_u%d_eps" % j] for j in range(nu)]
+        loss, _ = O.batch_loss_and_grads(p, users, eps, 0.2, 4, np.float32)
+        assert abs(loss - float(g["probe_loss"])) <= 1e-3 * abs(float(g["probe_loss"]))     # north-star loss gate
 
 
 @pytest.mark.parametrize("name", ["eval_val_I211", "eval_train_I211"])
