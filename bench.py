@@ -32,7 +32,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--items", type=int, default=20000)
+    ap.add_argument("--shape", default="ml-20m", choices=["ml-1m", "ml-20m", "netflix"],
+                    help="synthetic shape (synth.SHAPES); the default is the one BASELINE.json's metric is quoted on")
+    ap.add_argument("--items", type=int, default=None, help="catalogue size (default: the shape's)")
     ap.add_argument("--nplans", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true", help="do not bracket kernels with events (no roofline)")
@@ -62,8 +64,10 @@ def main():
     from svae_cf_amd import synth
     from svae_cf_amd.dist import GradSync, rank_batches
 
-    I, B = args.items, args.batch
-    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    _, shape_items, mu, sigma, lmax = synth.SHAPES[args.shape]
+    I, B = (args.items or shape_items), args.batch
+    shape_name = {"ml-1m": "ML-1M", "ml-20m": "ML-20M", "netflix": "Netflix"}[args.shape]
+    shape_cfg = {"ml-1m": 1, "ml-20m": 2, "netflix": 3}[args.shape]
     n_users = args.nplans * B * world
     users = synth.make_users(n_users, I, mu, sigma, lmax, seed=98765)
     rng = np.random.default_rng(98765)
@@ -195,6 +199,8 @@ def main():
             pmc = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         pass
+    if args.shape != "ml-20m" or I != 20000:
+        pmc = {}                                        # the PMC passes were taken on the default workload only
     for tag, r in rooflines.items():
         if tag in pmc and "hbm_bytes" in pmc[tag]:      # per STEP, like avg_ms: bytes per launch x launches per step
             r["traffic"] = pmc[tag]["hbm_bytes"] * pmc[tag].get("launches_per_step", 1.0)
@@ -220,17 +226,18 @@ def main():
         from oracle import svae_torch as TP           # checker / baseline leg only
         cb = TP.time_cpu_baseline(users[:1200], I, next_k=4, warmup=3, budget_s=20.0, max_users=1000)
         cpu = dict(value=cb["value"], unit="sequences/s", cores=cb["cores"], kind="port",
-                   sample="%d users of the same synthetic ML-20M-shaped set, notebook-style B=1 fwd+bwd+Adam "
-                          "(dense fp32, torch CPU), %.1f s" % (cb["users"], cb["seconds"]))
+                   sample="%d users of the same synthetic %s-shaped set, notebook-style B=1 fwd+bwd+Adam "
+                          "(dense fp32, torch CPU), %.1f s" % (cb["users"], shape_name, cb["seconds"]))
 
     if rank == 0:
         out = {
-            "metric": "train sequences/sec (ML-20M shape)", "value": total_users / dt, "unit": "sequences/s",
+            "metric": "train sequences/sec (%s shape)" % shape_name, "value": total_users / dt, "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
-            "config": {"workload": "ML-20M-shaped synthetic (configs[2]): 20000 items, seq<=200, "
-                                   "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam" % B,
+            "config": {"workload": "%s-shaped synthetic (configs[%d]): %d items, seq<=%d, "
+                                   "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam"
+                                   % (shape_name, shape_cfg, I, lmax, B),
                        "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "mean_rows_bracketed_steps": rows_timed, "parallelism": "dp%d" % world,
                        "final_loss": loss, "side_stream": eng.side_stream_info},
             "kernel_ms": kt, "kernel_timing": "HIP events on the launch streams over a replay of the first %d timed steps "
