@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Agreement between bench.py's kernel_ms (HIP events / dispatch timestamps in the replay pass) and the rocprofv3
+kernel trace of the SAME command:  tools/prof_agree.py <bench.json> <kernel_stats.csv> [steps_in_trace]
+Per-step milliseconds from the trace = TotalDurationNs / steps in the trace (warm-up + timed + replay)."""
+import csv
+import json
+import sys
+
+bench = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+rows = list(csv.DictReader(open(sys.argv[2])))
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else bench["warmup"] + 2 * bench["steps"]
+tot = {}
+for r in rows:
+    tot[r["Name"]] = tot.get(r["Name"], 0.0) + float(r["TotalDurationNs"])
+
+
+def trace_ms(*subs):
+    return sum(v for k, v in tot.items() if any(s in k for s in subs)) / steps * 1e-6
+
+
+pairs = [("proj_fdh_fused", ("proj_kernel<1>",)), ("proj_dw_fused", ("proj_kernel<2>",)),
+         ("gru_fwd", ("gru_fwd_bf16_kernel",)), ("gru_bwd", ("gru_bwd_bf16_kernel",)),
+         ("wgrad", ("wgrad_kernel",)), ("gi_gemm", ("rowgemm_kernel<0",)), ("demb_gemm", ("rowgemm_kernel<1",)),
+         ("mlp_fwd", ("mlp_fwd_kernel",)), ("mlp_bwd", ("mlp_bwd_kernel",))]
+print("| kernel (bench tag) | bench.py kernel_ms (per step) | rocprofv3 trace (per step) | ratio |")
+print("|---|---|---|---|")
+for tag, subs in pairs:
+    if tag in bench["kernel_ms"]:
+        a, b = bench["kernel_ms"][tag], trace_ms(*subs)
+        print("| %s | %.4f | %.4f | %.3f |" % (tag, a, b, a / b if b else float("nan")))
+print("\nsteps in the trace: %d; bench: %.0f seq/s, %.4f ms/step" % (steps, bench["value"], bench["ms_per_step"]))
