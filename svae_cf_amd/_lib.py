@@ -51,6 +51,7 @@ SIGNATURES = {
     "svae_mlp_frag_elems": [],
     "svae_mlp_prep": [_P, _P, _P, _P, _P],
     "svae_mlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "svae_mlp_fwd_prep": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "svae_mlp_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "svae_spin": [_I, _P],
     "svae_event_create": [_P],

@@ -143,15 +143,38 @@ struct MlpFwdArgs {
     float* d1;              // [R][160]
     float* kl_row;          // [R]
     int R;
+    // PREP only: the projection sweeps' bf16 operand copies of d1 (what svae_proj_prep_rows_range makes from d1)
+    unsigned short* h2b;    // [R_pad][160]  plain copy + constant columns
+    unsigned short* h2s;    // [R_pad][160]  copy scaled by log2(e) + constant columns
+    unsigned short* h2tb;   // [160][R_pad]  transpose of h2b, rows in the sweeps' k order
+    int row0, row1, ldt;    // rows [row0, row1) are written (row1 may reach into the pad rows R..R_pad)
 };
 
+// K-pad constant columns of the projection operands (the same numbers as csrc/proj.hip's file header)
+constexpr int PC_ONE = 150, PC_BH = 151, PC_BL = 152, PC_RH = 153;
+constexpr float P_LOG2E = 1.4426950408889634f, P_NEG_BIG = -1.0e30f;
+__device__ __forceinline__ int prep_korder(int y) { return (y & ~12) | ((y & 4) << 1) | ((y & 8) >> 1); }
+// (plain, scaled) bf16 of element (row, column c) of the decoder hidden, as proj_prep_kernel<1> writes them
+__device__ __forceinline__ void prep_vals(int c, float v, bool live, unsigned short& hp, unsigned short& hs) {
+    const unsigned short one = 0x3F80;
+    hp = 0; hs = 0;
+    if (c < SV_D) {
+        if (live) { hp = sv_f2bf(v); hs = sv_f2bf(v * P_LOG2E); }
+    } else {
+        if (c == PC_ONE) hp = live ? one : 0;
+        if (c == PC_BH || c == PC_BL) { hp = live ? one : 0; hs = live ? one : 0; }
+        if (c == PC_RH) hp = live ? 0 : sv_f2bf(P_NEG_BIG);
+    }
+}
+
+template <bool PREP>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wlds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int r = (blockIdx.x * 4 + wave) * 32 + li;
-    const bool ok = r < a.R;
+    const int r = (PREP ? a.row0 : 0) + (blockIdx.x * 4 + wave) * 32 + li;
+    const bool ok = r < a.R && (!PREP || r < a.row1);
     const size_t rc = ok ? r : a.R - 1;          // loads are clamped, stores masked
 
     // ---- encoder: enc^T = tanh(W1 hs^T + b1)
@@ -219,6 +242,26 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) c[i] = sv_tanh_fast(c[i]);
         tile_store(a.d1 + rc * SV_DP, nt, lh, c, ok);
+        if (PREP && r < a.row1) {
+            // the sweeps' operand copies straight from the accumulators (same values as a conversion of the d1 just
+            // stored): 8-byte row-major stores; the transpose goes out as 2-byte stores, 32 consecutive rows of one
+            // column per half-wave
+            const int kr = prep_korder(r);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned short hp[4], hs[4];
+                const int c0 = 32 * nt + 8 * g + 4 * lh;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) prep_vals(c0 + i, c[4 * g + i], ok, hp[i], hs[i]);
+                uint2 up, us;
+                up.x = hp[0] | ((unsigned)hp[1] << 16); up.y = hp[2] | ((unsigned)hp[3] << 16);
+                us.x = hs[0] | ((unsigned)hs[1] << 16); us.y = hs[2] | ((unsigned)hs[3] << 16);
+                *reinterpret_cast<uint2*>(a.h2b + (size_t)r * SV_DP + c0) = up;
+                *reinterpret_cast<uint2*>(a.h2s + (size_t)r * SV_DP + c0) = us;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a.h2tb[(size_t)(c0 + i) * a.ldt + kr] = hp[i];
+            }
+        }
     }
 }
 
@@ -340,14 +383,39 @@ extern "C" int svae_mlp_fwd(const float* hs, const float* eps, const void* frags
                             void* stream) {
     SV_CHECK_ARG(hs && eps && frags && b1 && bl && b2 && enc && tmp && z && d1 && kl_row, "svae_mlp_fwd: null pointer");
     SV_CHECK_ARG(R > 0, "svae_mlp_fwd: R = %d", R);
-    MlpFwdArgs a{hs, eps, (const unsigned short*)frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R};
+    MlpFwdArgs a{hs, eps, (const unsigned short*)frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R, nullptr, nullptr, nullptr, 0, 0, 0};
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_FWD * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_FWD * 1024);
         if (e != hipSuccess) return svae_fail((int)e, "svae_mlp_fwd: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(mlp_fwd_kernel, dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_FWD * 1024, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_FWD * 1024, (hipStream_t)stream, a);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same chain over rows [row0, row1) of the batch, which ALSO writes the projection sweeps' bf16 operand copies of
+// its last output (h2b, h2s, h2tb: what svae_proj_prep_rows_range(d1, R, R_pad, row0, row1, ...) makes from d1,
+// bit for bit) -- one kernel and one read of d1 less on the decoder side's critical chain.  All pointers are the
+// arrays' bases (row 0); row0 % 32 == 0; row1 <= R_pad may reach into the pad rows, which get the non-live constants.
+extern "C" int svae_mlp_fwd_prep(const float* hs, const float* eps, const void* frags, const float* b1, const float* bl,
+                                 const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R,
+                                 int R_pad, int row0, int row1, void* h2b, void* h2s, void* h2tb, void* stream) {
+    SV_CHECK_ARG(hs && eps && frags && b1 && bl && b2 && enc && tmp && z && d1 && kl_row && h2b && h2s && h2tb,
+                 "svae_mlp_fwd_prep: null pointer");
+    SV_CHECK_ARG(R > 0 && R_pad >= R && (R_pad % 64) == 0 && row0 >= 0 && row0 < row1 && row1 <= R_pad && (row0 % 32) == 0 &&
+                 row0 < R, "svae_mlp_fwd_prep: bad range [%d, %d) of %d (%d)", row0, row1, R, R_pad);
+    MlpFwdArgs a{hs, eps, (const unsigned short*)frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R, (unsigned short*)h2b,
+                 (unsigned short*)h2s, (unsigned short*)h2tb, row0, row1, R_pad};
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_FWD * 1024);
+        if (e != hipSuccess) return svae_fail((int)e, "svae_mlp_fwd_prep: LDS attribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3((row1 - row0 + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_FWD * 1024,
+                       (hipStream_t)stream, a);
     SV_LAUNCH_CHECK();
     return 0;
 }

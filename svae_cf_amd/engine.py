@@ -117,6 +117,7 @@ class SVAEEngine:
         # and the step does not wait for it -- it finishes under the next step's embedding / input GEMM / first
         # recurrence range, which leave most of the GPU idle, and the next step waits for it before its decoder side
         self.float_w3 = os.environ.get("SVAE_FLOAT_W3", "1") == "1"
+        self.fused_prep = os.environ.get("SVAE_FUSED_PREP", "1") == "1"
         self._in_step = False
         self._float_pending = False
         self._float_plan = None
@@ -492,10 +493,20 @@ class SVAEEngine:
         + dL/dh sweep of the projection and its finish.  Every array is row-major, so a row range is a pointer
         offset; the slab scratch of a range starts where the previous range's ends."""
         w, R, n = self.ws, plan.R, r1 - r0
-        self._mlp_fwd_rows(r0, r1)
         Rp = (R + 63) // 64 * 64
-        _lib.call("svae_proj_prep_rows_range", w["d1"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
-                  w["h2b"].data_ptr(), w["h2s"].data_ptr(), w["h2tb"].data_ptr(), _stream())
+        if self.fused_prep:
+            # MLP chain and the sweeps' operand copies in one kernel (svae_mlp_fwd_prep)
+            ev = self._tic("mlp_fwd")
+            _lib.call("svae_mlp_fwd_prep", w["hs"].data_ptr(), w["eps"].data_ptr(), self.mlp_frags.data_ptr(),
+                      self.P("encoder.linear1.bias").data_ptr(), self.P("linear1.bias").data_ptr(),
+                      self.P("decoder.linear1.bias").data_ptr(), w["enc"].data_ptr(), w["tmp"].data_ptr(),
+                      w["z"].data_ptr(), w["d1"].data_ptr(), w["kl_row"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
+                      w["h2b"].data_ptr(), w["h2s"].data_ptr(), w["h2tb"].data_ptr(), _stream())
+            self._toc("mlp_fwd", ev)
+        else:
+            self._mlp_fwd_rows(r0, r1)
+            _lib.call("svae_proj_prep_rows_range", w["d1"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
+                      w["h2b"].data_ptr(), w["h2s"].data_ptr(), w["h2tb"].data_ptr(), _stream())
         nsm = _lib.load().svae_proj_ns_max()
         args = (w["h2s"].data_ptr() + 2 * DP * r0, w["h2b"].data_ptr() + 2 * DP * r0, self.w3b.data_ptr(),
                 self.w3tb.data_ptr(), self.IPAD, w["d1"].data_ptr() + 4 * DP * r0,

@@ -168,3 +168,38 @@ def test_gru_gradient_array_forms_agree():
             assert d <= 1e-3 * float(grads[1][k].abs().max()), (k, d)
         else:
             assert torch.equal(grads[1][k], grads[2][k]), ("merged bf16 array", k)
+
+
+def test_fused_operand_copies_equal_the_two_kernel_path():
+    """svae_mlp_fwd_prep (MLP chain + the sweeps' bf16 operand copies in one kernel) against svae_mlp_fwd followed by
+    svae_proj_prep_rows_range, on a two-range forward of an ML-20M-shaped batch whose row count is not a multiple of
+    64: h2b / h2s / h2tb, d1 and the loss bit-identical, gradients bit-identical."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    I, B = 20000, 256
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(2048, I, mu, sigma, lmax, seed=98765)
+    idx = None
+    for cand in synth.bucketed_batches([len(u) for u in users], B, np.random.default_rng(1)):
+        plan = S.build_plan([users[i] for i in cand], 4, user_keys=cand, device="cuda", total_items=I)
+        if plan.split_t > 0 and plan.R % 64 != 0:
+            idx = cand
+            break
+    assert idx is not None, "no batch with a time split and a ragged row count"
+    eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+    _init(eng, 11)
+    eng.prepare(plan)
+    Rp = (plan.R + 63) // 64 * 64
+    got = {}
+    for fused in (False, True):
+        eng.fused_prep = fused
+        for name in ("h2b", "h2s", "h2tb", "d1"):
+            eng.ws[name].zero_() if name in eng.ws else None
+        loss = eng.forward(plan, 0.05, seed=7, step=3).clone()
+        eng.backward()
+        torch.cuda.synchronize()
+        got[fused] = dict(loss=loss, grads=eng.grads.clone(), d1=eng.ws["d1"][:plan.R * 160].clone(),
+                          h2b=eng.ws["h2b"][:Rp * 160].clone(), h2s=eng.ws["h2s"][:Rp * 160].clone(),
+                          h2tb=eng.ws["h2tb"][:Rp * 160].clone())
+    for k in got[False]:
+        assert torch.equal(got[False][k], got[True][k]), k
