@@ -31,7 +31,7 @@ def _init_sd(layout):
     return {n: torch.randn(s, generator=g) * 0.1 for n, s in layout.ref_shapes.items()}
 
 
-def _run(rank, world, prec, port, q):
+def _run(rank, world, prec, port, q, opt="adam"):
     sys.path.insert(0, ROOT)
     if q is not None:
         # a rank that stops making progress dumps its stacks and exits instead of hanging the test run
@@ -50,6 +50,8 @@ def _run(rank, world, prec, port, q):
     lens = [len(u) for u in users]
     eng = S.SVAEEngine(I, device="cuda", prec=prec)
     eng.load_state_dict(_init_sd(eng.layout))
+    if opt == "adagrad":        # nb:1252-1255: the gradient scale 1/world goes through svae_optimizer_step as well
+        eng.set_optimizer("adagrad", 0.01, 5e-3, decay=0.0, eps=1e-10)
     steps = synth.bucketed_batches(lens, B, np.random.default_rng(11), world=WORLD)
     mine = rank_batches(lens, B, np.random.default_rng(11), rank, WORLD) if world > 1 else None
     if world > 1:
@@ -81,14 +83,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("prec", [0, 1])
-def test_two_ranks_equal_union_batch(prec):
+@pytest.mark.parametrize("prec,opt", [(0, "adam"), (1, "adam"), (0, "adagrad")])
+def test_two_ranks_equal_union_batch(prec, opt):
     import torch.multiprocessing as mp
-    ref_sd, ref_losses = _run(0, 1, prec, 0, None)
+    ref_sd, ref_losses = _run(0, 1, prec, 0, None, opt)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_run, args=(r, WORLD, prec, port, q), daemon=True) for r in range(WORLD)]
+    ps = [ctx.Process(target=_run, args=(r, WORLD, prec, port, q, opt), daemon=True) for r in range(WORLD)]
     for p in ps:
         p.start()
     try:
