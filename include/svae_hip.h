@@ -218,6 +218,16 @@ int svae_optimizer_step(int kind, float* p, const float* g, float* a, float* b, 
 int svae_masked_topk(const float* scores, int ld, const int* seen, const int* seen_off, int n_users, int I, int K,
                      int* out_idx, float* out_val, float* work, void* stream);
 
+/* No counterpart in the reference.  svae_masked_topk for callers that CANNOT ALLOCATE the `work` buffer: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernel and results; the scratch is
+ * a static device array inside the library (32 MiB per GPU, held until the process ends): n_users * ld <= 8 Mi
+ * floats (e.g. 256 users x 20 032, 8 users x 1 000 000), larger calls are refused (rc < 0).  No hipMalloc / hipFree /
+ * allocating routine is called.  The stream must belong to the current device; svae_check_device() on that device
+ * beforehand does the one-time address look-up (otherwise the first call does).  Calls that overlap on one GPU
+ * share the array and race: keep them on one stream. */
+int svae_masked_topk_static(const float* scores, int ld, const int* seen, const int* seen_off, int n_users, int I,
+                            int K, int* out_idx, float* out_val, void* stream);
+
 /* ---- helpers -------------------------------------------------------------------------------------------- */
 int svae_colsum(const float* a, float* out, float* partials, int R, int N, int ld, int nparts, void* stream);
 int svae_transpose(const float* in, float* out, int rows, int cols, void* stream);

@@ -29,5 +29,7 @@ extern "C" int svae_check_device(void) {
     if (e != hipSuccess) return svae_fail((int)e, "svae_check_device: %s", hipGetErrorString(e));
     if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
         return svae_fail(-2, "svae_check_device: built for gfx950, device is %s", p.gcnArchName);
-    return 0;
+    // the library's set-up call for this device: look up the static scratch of svae_masked_topk_static here, so
+    // that entry point has nothing left to set up when it is called from code that must not touch the runtime
+    return svae_scratch_setup(nullptr);
 }

@@ -26,6 +26,8 @@ typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 
 extern thread_local char g_svae_err[512];
 int svae_fail(int code, const char* fmt, ...);
+// ops.hip: per-device address of the static scratch of svae_masked_topk_static (current device); out may be NULL
+int svae_scratch_setup(float** out);
 
 #define SV_CHECK_ARG(cond, ...)                         \
     do {                                                \

@@ -1,6 +1,8 @@
 // HBM-bound kernels of the SVAE step for gfx950: embedding gather / segmented scatter-add, latent
 // reparameterisation + KL, row log-softmax + next-k NLL over materialised logits, fused Adam(L2),
 // column sums (bias gradients), masked top-k, Philox normal noise, small helpers.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -804,6 +806,61 @@ extern "C" int svae_masked_topk(const float* scores, int ld, const int* seen, co
                                 int K, int* out_idx, float* out_val, float* work, void* stream) {
     SV_CHECK_ARG(scores && seen && seen_off && out_idx && out_val && work, "svae_masked_topk: null pointer");
     SV_CHECK_ARG(n_users > 0 && I > 0 && ld >= I && K >= 1 && K <= I, "svae_masked_topk: bad shape");
+    hipLaunchKernelGGL(masked_topk_kernel, dim3(n_users), dim3(1024), 0, (hipStream_t)stream, scores, ld, seen,
+                       seen_off, I, K, out_idx, out_val, work);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the same top-k for callers that cannot allocate (no counterpart in the reference) -----------------------
+// svae_masked_topk takes its scratch copy of the scores (`work`) from the caller, who has to allocate it.  Code under
+// HIP graph capture, a tight serving loop or a harness that forbids hipMalloc cannot: svae_masked_topk_static runs the
+// same kernel with the scratch in a file-scope device array.  Every GPU the library runs on holds its own copy of the
+// array (32 MiB) at its own address until the process ends; the address is looked up once per device, with that device
+// current (svae_scratch_setup, called by svae_check_device and, if that was skipped, by the first call on a device).
+// In host code the array's NAME is only a handle for hipGetSymbolAddress: kernels get the looked-up pointer.
+constexpr long long TOPK_STATIC_FLOATS = 8ll << 20;
+static __device__ __align__(256) float scratch[TOPK_STATIC_FLOATS];
+
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static float* g_scratch_ptr[SCRATCH_MAX_DEVICES] = {nullptr};
+
+// Address of `scratch` on the CURRENT device (looked up on first use; no allocation: the array is part of the loaded
+// code object).  Returns 0 and sets *out, or a svae_fail code.
+int svae_scratch_setup(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return svae_fail((int)e, "svae_scratch_setup: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) return svae_fail(-1, "svae_scratch_setup: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr)
+            return svae_fail(e != hipSuccess ? (int)e : -3, "svae_scratch_setup: hipGetSymbolAddress(scratch) on device %d: %s",
+                             dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    if (out) *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+// No counterpart in the reference: svae_masked_topk (nb:621-636) for callers that cannot allocate.  Same arguments
+// without `work`; n_users * ld must not exceed the static scratch (8 Mi floats).  The stream must belong to the current
+// device.  Calls that overlap on one GPU (two streams) race on the array; nothing in it has to start at zero (the
+// kernel writes every element of a row's copy before it reads it), so the last call's contents do not matter.
+extern "C" int svae_masked_topk_static(const float* scores, int ld, const int* seen, const int* seen_off, int n_users,
+                                       int I, int K, int* out_idx, float* out_val, void* stream) {
+    SV_CHECK_ARG(scores && seen && seen_off && out_idx && out_val, "svae_masked_topk_static: null pointer");
+    SV_CHECK_ARG(n_users > 0 && I > 0 && ld >= I && K >= 1 && K <= I, "svae_masked_topk_static: bad shape");
+    SV_CHECK_ARG((long long)n_users * (long long)ld <= TOPK_STATIC_FLOATS,
+                 "svae_masked_topk_static: n_users * ld = %lld floats exceeds the static scratch of %lld floats "
+                 "(32 MiB): score fewer users per call or use svae_masked_topk with a caller-owned work buffer",
+                 (long long)n_users * (long long)ld, TOPK_STATIC_FLOATS);
+    float* work = nullptr;
+    const int rc = svae_scratch_setup(&work);
+    if (rc != 0) return rc;
     hipLaunchKernelGGL(masked_topk_kernel, dim3(n_users), dim3(1024), 0, (hipStream_t)stream, scores, ld, seen,
                        seen_off, I, K, out_idx, out_val, work);
     SV_LAUNCH_CHECK();
