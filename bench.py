@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the SVAE training step on MI355X (contract: see the task's bench.py section).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--prec bf16|fp32] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--prec bf16|fp32] [--batch B] [--shape ...]
+
+``--gpus N`` with N > 1 and no launcher around it (WORLD_SIZE unset): this process starts N rank processes itself
+(one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) BEFORE it touches the GPU and
+relays rank 0's JSON line; under ``python -m torch.distributed.run`` it is one of the ranks, as before.
 
 A "step" = forward + backward + (gradient all-reduce) + Adam over one length-bucketed batch of
 B users per GPU, synthetic ML-20M-shaped sequences (138k users / 20k items / <=200 items per user;
@@ -25,6 +29,27 @@ sys.path.insert(0, ROOT)
 PEAK = {"hbm": 8000.0, "bf16": 2500.0, "fp32": 157.3}
 
 
+def spawn_ranks(n):
+    """Start n rank processes of this script (no torchrun needed) and relay what they print.  Nothing here touches
+    the GPU: the children initialise it.  Returns the largest exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -32,13 +57,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--shape", default="ml-20m", choices=["ml-1m", "ml-20m", "netflix"],
+    ap.add_argument("--shape", default="ml-20m", choices=["ml-1m", "ml-20m", "netflix", "large"],
                     help="synthetic shape (synth.SHAPES); the default is the one BASELINE.json's metric is quoted on")
     ap.add_argument("--items", type=int, default=None, help="catalogue size (default: the shape's)")
     ap.add_argument("--nplans", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true", help="do not bracket kernels with events (no roofline)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions in all: the first is the contractual one (`value`), the others give the spread")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -66,8 +96,8 @@ def main():
 
     _, shape_items, mu, sigma, lmax = synth.SHAPES[args.shape]
     I, B = (args.items or shape_items), args.batch
-    shape_name = {"ml-1m": "ML-1M", "ml-20m": "ML-20M", "netflix": "Netflix"}[args.shape]
-    shape_cfg = {"ml-1m": 1, "ml-20m": 2, "netflix": 3}[args.shape]
+    shape_name = {"ml-1m": "ML-1M", "ml-20m": "ML-20M", "netflix": "Netflix", "large": "large-catalogue"}[args.shape]
+    shape_cfg = {"ml-1m": 1, "ml-20m": 2, "netflix": 3, "large": 4}[args.shape]
     n_users = args.nplans * B * world
     users = synth.make_users(n_users, I, mu, sigma, lmax, seed=98765)
     rng = np.random.default_rng(98765)
@@ -117,27 +147,43 @@ def main():
                 "proj_dw_finish", "proj_dw", "proj_dx", "softmax_nll", "gru_fwd", "gru_fwd2", "gru_bwd", "gi_gemm",
                 "demb_gemm"]
     eng.prof = None
-    barrier()
-    t0 = time.perf_counter()
-    users_done = 0
-    rows_done = 0
     first_step = step
-    for i in range(args.steps):
-        p = plans[step % len(plans)]
-        eng.train_step(p, 0.01, seed=1234)
-        users_done += p.B
-        rows_done += p.R
-        step += 1
-    t_enq = time.perf_counter() - t0
-    barrier()
-    dt = time.perf_counter() - t0
+
+    def timed_region(step):
+        """EXACTLY args.steps steps between barrier + synchronize on both sides."""
+        barrier()
+        t0 = time.perf_counter()
+        users_done = rows_done = 0
+        for i in range(args.steps):
+            p = plans[step % len(plans)]
+            eng.train_step(p, 0.01, seed=1234)
+            users_done += p.B
+            rows_done += p.R
+            step += 1
+        t_enq = time.perf_counter() - t0
+        barrier()
+        return time.perf_counter() - t0, t_enq, users_done, rows_done, step
+
+    dt, t_enq, users_done, rows_done, step = timed_region(step)
     loss = float(eng.loss_out[0])
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     u = torch.tensor([float(users_done)], dtype=torch.float64, device=dev)
+    dt_ranks = [dt]
     if world > 1 or rehearse:
+        gathered = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, t)
+        dt_ranks = [float(g_[0]) for g_ in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
     dt, total_users = float(t[0]), float(u[0])
+    # the same region again (same plans: the step counter continues through the cycle): spread of the measurement
+    region_ms = [dt / args.steps * 1e3]
+    for _ in range(max(0, args.repeats - 1)):
+        d2, _, _, _, step = timed_region(step)
+        t2 = torch.tensor([d2], dtype=torch.float64, device=dev)
+        if world > 1 or rehearse:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        region_ms.append(float(t2[0]) / args.steps * 1e3)
 
     # (per STEP: a kernel launched twice in a step -- the forward sweep and the recurrence run in two time ranges --
     # counts with the sum of its launches)
@@ -175,7 +221,9 @@ def main():
         rows = rows_timed if tag in kt else rows_untimed
         pf = 300.0 * I * rows
         return {
-            "proj_fwd": ("mfma", pf), "proj_fdh_fused": ("mfma", 2 * pf), "proj_dw_fused": ("mfma", 2 * pf),
+            # per kernel: forward+dL/dh sweep = 2 algorithmic contractions; weight-gradient sweep = 1 (its logit
+            # recompute is executed, not algorithmic work)
+            "proj_fwd": ("mfma", pf), "proj_fdh_fused": ("mfma", 2 * pf), "proj_dw_fused": ("mfma", pf),
             "proj_dw": ("mfma", pf), "proj_dx": ("mfma", pf),
             "gru_fwd": ("mfma", 240000.0 * rows), "gru_bwd": ("mfma", 240000.0 * rows),
             "softmax_nll": ("hbm", rows * I * 4 * 2 + rows * 4 * 4),
@@ -195,7 +243,9 @@ def main():
     # gfx950 correction of MI355X_MICROARCH.md; separate --pmc runs), committed under profiles/.
     pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_proj.json")) as f:
+        name = "r02_pmc_proj.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_proj.json")) \
+            else "r01_pmc_proj.json"
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             pmc = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         pass
@@ -205,19 +255,26 @@ def main():
         if tag in pmc and "hbm_bytes" in pmc[tag]:      # per STEP, like avg_ms: bytes per launch x launches per step
             r["traffic"] = pmc[tag]["hbm_bytes"] * pmc[tag].get("launches_per_step", 1.0)
     # The dominant kernel is the projection sweep, proj_kernel<MODE> (csrc/proj.hip): launched twice per step
-    # (forward + dL/dh sweep, dL/dW sweep), together the largest share of the step.  Its line covers both
-    # launches: 4 projection-sized contractions per step over the sum of the two durations.  The GRU recurrence
-    # kernels are listed in "rooflines" for completeness: they are bound by per-timestep latency, not by MFMA rate.
+    # (forward + dL/dh sweep, dL/dW sweep), together the largest share of the step.  Its line covers both launches.
+    # ALGORITHMIC work: the projection is 300*I flop per row forward, x3 for training = three
+    # projection-sized contractions per step (logits, dL/dh2 = P W3, dL/dW3 = P^T h2).  The kernels EXECUTE four: the
+    # weight-gradient sweep recomputes the logits instead of reading them back (they are never materialised); that
+    # figure is reported under "executed", it is not the roofline fraction.
+    # The GRU recurrence kernels are listed in "rooflines" for completeness: they are bound by per-timestep latency.
     roofline = None
     if "proj_fdh_fused" in kt and "proj_dw_fused" in kt:
         ms = kt["proj_fdh_fused"] + kt["proj_dw_fused"]
-        ach = 4 * proj_flop / (ms * 1e-3) / 1e12
+        ach = 3 * proj_flop / (ms * 1e-3) / 1e12
+        exe = 4 * proj_flop / (ms * 1e-3) / 1e12
         tr = None
         if "traffic" in rooflines["proj_fdh_fused"] and rooflines["proj_fdh_fused"]["traffic"] and \
                 rooflines["proj_dw_fused"]["traffic"]:
             tr = rooflines["proj_fdh_fused"]["traffic"] + rooflines["proj_dw_fused"]["traffic"]
         roofline = dict(bound="mfma", kernel="proj_kernel (fdh + dw sweeps of one step)", achieved=ach,
-                        peak=PEAK[args.prec], unit="TFLOP/s", frac=ach / PEAK[args.prec], traffic=tr, avg_ms=ms)
+                        peak=PEAK[args.prec], unit="TFLOP/s", frac=ach / PEAK[args.prec], traffic=tr, avg_ms=ms,
+                        algorithmic_flop=3 * proj_flop,
+                        executed=dict(achieved=exe, frac=exe / PEAK[args.prec], flop=4 * proj_flop,
+                                      note="incl. the logit recompute of the weight-gradient sweep"))
     elif rooflines:
         roofline = rooflines[max(rooflines, key=lambda k: rooflines[k]["avg_ms"])]
 
@@ -232,8 +289,12 @@ def main():
     if rank == 0:
         out = {
             "metric": "train sequences/sec (%s shape)" % shape_name, "value": total_users / dt, "unit": "sequences/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "ranks_in_process_group": (dist.get_world_size() if (world > 1 or rehearse) else 1),
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "ms_per_step_by_rank": [d / args.steps * 1e3 for d in dt_ranks],
+            "ms_per_step_regions": dict(n=len(region_ms), min=float(np.min(region_ms)),
+                                        median=float(np.median(region_ms)), max=float(np.max(region_ms)),
+                                        note="the timed region repeated; `value` is the first one"), "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "%s-shaped synthetic (configs[%d]): %d items, seq<=%d, "
                                    "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam"

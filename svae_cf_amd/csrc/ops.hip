@@ -162,21 +162,30 @@ __global__ __launch_bounds__(256) void softmax_nll_kernel(float* __restrict__ lo
         float S = 0.f;
         for (int w = 0; w < 4; ++w) S += red[4 + w] * expf(red[w] - M);
         bc[0] = M + logf(S);
-        // targets: -1 = padding.  duplicates were removed on the host (the reference's scatter_ of 1.0
-        // makes a duplicate count once, nb:510-513)
-        float nll = 0.f;
-        int nr = 0;
-        for (int k = 0; k < K; ++k) {
-            const int it = tgt[(size_t)row * K + k];
-            if (it >= 0) { nll += bc[0] - lr[it]; ++nr; }
-        }
-        nll_row[row] = nll;
-        bc[1] = (float)nr;
         if (lse_out) lse_out[row] = bc[0];
     }
     __syncthreads();
-    if (!WRITE_GRAD) return;
     const float lse = bc[0];
+    // targets: -1 = padding.  duplicates were removed on the host (the reference's scatter_ of 1.0 makes a
+    // duplicate count once, nb:510-513).  Any K: `postfix` rows have up to T - 1 targets (nb:515-519); thread t
+    // takes targets t, t + 256, ...; partial sums are combined in a fixed order.
+    {
+        float nll = 0.f, nr = 0.f;
+        for (int k = tid; k < K; k += 256) {
+            const int it = tgt[(size_t)row * K + k];
+            if (it >= 0) { nll += lse - lr[it]; nr += 1.f; }
+        }
+        nll = sv_wave_sum(nll);
+        nr = sv_wave_sum(nr);
+        if (lane == 0) { red[wave] = nll; red[4 + wave] = nr; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        nll_row[row] = (red[0] + red[1]) + (red[2] + red[3]);
+        bc[1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+    __syncthreads();
+    if (!WRITE_GRAD) return;
     const float w = w_nll[row];
     const float c = bc[1] * w;
     for (int i = tid; i < n4; i += 256) {
@@ -186,8 +195,8 @@ __global__ __launch_bounds__(256) void softmax_nll_kernel(float* __restrict__ lo
     }
     for (int i = (n4 << 2) + tid; i < ldI; i += 256) lr[i] = i < I ? c * expf(lr[i] - lse) : 0.f;
     __syncthreads();
-    if (tid < K) {
-        const int it = tgt[(size_t)row * K + tid];
+    for (int k = tid; k < K; k += 256) {
+        const int it = tgt[(size_t)row * K + k];
         if (it >= 0) lr[it] -= w;
     }
 }
@@ -703,7 +712,7 @@ extern "C" int svae_latent_bwd(const float* tmp, const float* eps, const float* 
 extern "C" int svae_softmax_nll(float* logits, const int* tgt, const float* w_nll, float* nll_row, float* lse,
                                 int R, int I, int ldI, int K, int write_grad, void* stream) {
     SV_CHECK_ARG(logits && tgt && nll_row && R > 0 && I > 0, "svae_softmax_nll: bad arguments");
-    SV_CHECK_ARG(ldI >= I && (ldI % 4) == 0 && K >= 1 && K <= 256, "svae_softmax_nll: bad ldI=%d / K=%d", ldI, K);
+    SV_CHECK_ARG(ldI >= I && (ldI % 4) == 0 && K >= 1, "svae_softmax_nll: bad ldI=%d / K=%d", ldI, K);
     SV_CHECK_ARG(!write_grad || w_nll, "svae_softmax_nll: w_nll required for the gradient");
     if (write_grad)
         hipLaunchKernelGGL(softmax_nll_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, tgt, w_nll,

@@ -33,6 +33,7 @@ struct RgArgs {
     float* y;                     // [R][N]
     int R, nrb;                   // rows, row blocks of 128
     int ldx;                      // row stride of x (floats, >= K)
+    const unsigned short* frags_lo;   // SPLIT: the lo parts of the weight, same fragment order (read from L2, not staged)
 };
 
 __device__ __forceinline__ unsigned rg_pk2(float a, float b) {
@@ -62,8 +63,12 @@ __device__ __forceinline__ void rg_glds16(const char* g, char* l) {
 // Grid: id -> (row block, chunk) with the chunks of a row block 8 ids apart, i.e. on the same XCD (id % 8) and
 // dispatched together: the row block is then read from HBM once and from that XCD's L2 by the other chunks.
 // XB: x holds bf16 elements (ldx in elements): a k-step of a lane is one 16-byte load and needs no conversion.
-template <int WHICH, bool XB>
+// SPLIT (fp32 rows only): the parity instantiation.  Same tiling and fragment order; a product is carried as
+// hi*hi + hi*lo + lo*hi of bf16 hi / lo parts (rows split in registers, the weight's lo fragments read straight from
+// L2: the LDS is full of the hi fragments).
+template <int WHICH, bool XB, bool SPLIT = false>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
+    static_assert(!(XB && SPLIT), "the split instantiation reads fp32 rows");
     using S = RgShape<WHICH>;
     constexpr int K = S::K, N = S::N, CT = S::CT, XG = S::XG, PDX = S::PDX;
     constexpr int KS = K / 16, NT = N / 32, NCH = (NT + CT - 1) / CT, NG = KS / XG;
@@ -122,9 +127,22 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
             if (g + PDX < NG) RG_LOADX(g + PDX)
 #pragma unroll
             for (int s = 0; s < XG; ++s) {
-                bf16x8 xf;
+                bf16x8 xf, xl;
                 if (XB) {
                     xf = __builtin_bit_cast(bf16x8, xraw[g % (PDX + 1)][s][0]);
+                } else if (SPLIT) {
+                    const float4 lo = xraw[g % (PDX + 1)][s][0], hi = xraw[g % (PDX + 1)][s][XB ? 0 : 1];
+                    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    uint4 u, w;
+                    u.x = rg_pk2(v[0], v[1]); u.y = rg_pk2(v[2], v[3]); u.z = rg_pk2(v[4], v[5]); u.w = rg_pk2(v[6], v[7]);
+                    const unsigned hw[4] = {u.x, u.y, u.z, u.w};
+                    unsigned lw[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        lw[i] = rg_pk2(v[2 * i] - __uint_as_float(hw[i] << 16), v[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u));
+                    w.x = lw[0]; w.y = lw[1]; w.z = lw[2]; w.w = lw[3];
+                    xf = __builtin_bit_cast(bf16x8, u);
+                    xl = __builtin_bit_cast(bf16x8, w);
                 } else {
                     const float4 lo = xraw[g % (PDX + 1)][s][0], hi = xraw[g % (PDX + 1)][s][1];
                     uint4 u;
@@ -135,6 +153,12 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
 #pragma unroll
                 for (int t = 0; t < NTC; ++t) {
                     const bf16x8 wf = __builtin_bit_cast(bf16x8, st[(ks * NTC + t) * 64]);
+                    if (SPLIT) {
+                        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(
+                            a.frags_lo + ((size_t)c * CT * KS + (size_t)ks * NTC + t) * 512 + lane * 8);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xf, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xl, acc[t], 0, 0, 0);
+                    }
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t], 0, 0, 0);
                 }
             }
@@ -165,7 +189,8 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
 // fp32 weight -> bf16 fragments in consumption order.  Element (n, k) of the weight the kernel multiplies by is
 // src[n * sn + k * sk]  (which 0: W_ih [672][256], sn = 256, sk = 1;  which 1: W_ih^T, sn = 1, sk = 256).
 template <int WHICH>
-__global__ void rowgemm_prep_kernel(const float* __restrict__ src, int sn, int sk, unsigned short* __restrict__ dst) {
+__global__ void rowgemm_prep_kernel(const float* __restrict__ src, int sn, int sk, unsigned short* __restrict__ dst,
+                                    unsigned short* __restrict__ dst_lo) {
     using S = RgShape<WHICH>;
     constexpr int KS = S::K / 16, NT = S::N / 32;
     const int f = blockIdx.x;                 // fragment id = tile * KS + ks
@@ -174,24 +199,29 @@ __global__ void rowgemm_prep_kernel(const float* __restrict__ src, int sn, int s
     unsigned short* d = dst + rg_frag_off<WHICH>(tile, ks) + lane * 8;
     const int n = 32 * tile + li, k0 = 16 * ks + 8 * lh;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] = sv_f2bf(src[(size_t)n * sn + (size_t)(k0 + j) * sk]);
+    for (int j = 0; j < 8; ++j) {
+        const float v = src[(size_t)n * sn + (size_t)(k0 + j) * sk];
+        const unsigned short h = sv_f2bf(v);
+        d[j] = h;
+        if (dst_lo) (dst_lo + (d - dst))[j] = sv_f2bf(v - sv_bf2f(h));
+    }
     (void)NT;
 }
 
-template <int WHICH, bool XB>
+template <int WHICH, bool XB, bool SPLIT = false>
 int rg_launch(RgArgs a, hipStream_t st) {
     using S = RgShape<WHICH>;
     constexpr int lds = S::CT * (S::K / 16) * 1024;
     constexpr int nch = (S::N / 32 + S::CT - 1) / S::CT;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)rowgemm_kernel<WHICH, XB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)rowgemm_kernel<WHICH, XB, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_rowgemm: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     a.nrb = (a.R + RG_ROWS - 1) / RG_ROWS;
     const int groups = (a.nrb + 7) / 8;                 // 8 row blocks (one per XCD) x nch chunks each
-    hipLaunchKernelGGL((rowgemm_kernel<WHICH, XB>), dim3(groups * nch * 8), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((rowgemm_kernel<WHICH, XB, SPLIT>), dim3(groups * nch * 8), dim3(256), lds, st, a);
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -203,16 +233,22 @@ extern "C" int svae_rowgemm_frag_elems(int which) {
 }
 
 // wih: gru.weight_ih_l0 as stored, [672][256] fp32 (gate rows padded 200 -> 224 with zeros).
-extern "C" int svae_rowgemm_prep(const float* wih, int which, void* frags, void* stream) {
-    SV_CHECK_ARG(wih && frags && (which == 0 || which == 1), "svae_rowgemm_prep: bad arguments");
+// prec 1: bf16 fragments (svae_rowgemm_frag_elems elements); prec 2: hi fragments followed by the lo fragments
+// (v - hi, rounded to bf16) for the split instantiation: 2 * svae_rowgemm_frag_elems elements.
+extern "C" int svae_rowgemm_prep_prec(const float* wih, int which, void* frags, int prec, void* stream) {
+    SV_CHECK_ARG(wih && frags && (which == 0 || which == 1) && (prec == 1 || prec == 2), "svae_rowgemm_prep: bad arguments");
+    unsigned short* lo = prec == 2 ? (unsigned short*)frags + SV_G * SV_E : nullptr;
     if (which == 0)
         hipLaunchKernelGGL(rowgemm_prep_kernel<0>, dim3((SV_G / 32) * (SV_E / 16)), dim3(64), 0, (hipStream_t)stream, wih,
-                           SV_E, 1, (unsigned short*)frags);
+                           SV_E, 1, (unsigned short*)frags, lo);
     else
         hipLaunchKernelGGL(rowgemm_prep_kernel<1>, dim3((SV_E / 32) * (SV_G / 16)), dim3(64), 0, (hipStream_t)stream, wih,
-                           1, SV_E, (unsigned short*)frags);
+                           1, SV_E, (unsigned short*)frags, lo);
     SV_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int svae_rowgemm_prep(const float* wih, int which, void* frags, void* stream) {
+    return svae_rowgemm_prep_prec(wih, which, frags, 1, stream);
 }
 
 // which 0: y [R][672] = x [R][256] W_ih^T + bias (bias may be NULL);  which 1: y [R][256] = x [R][672] W_ih.
@@ -225,13 +261,23 @@ extern "C" int svae_rowgemm(const float* x, const void* frags, const float* bias
 }
 
 // The same with rows of x ldx floats apart (dL/demb reads (dr, dz, dn) out of the merged [R][896] gradient array).
+extern "C" int svae_rowgemm_ld_prec(const float* x, int ldx, const void* frags, const float* bias, float* y, int R,
+                                    int which, int prec, void* stream);
 extern "C" int svae_rowgemm_ld(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,
                                void* stream) {
+    return svae_rowgemm_ld_prec(x, ldx, frags, bias, y, R, which, 1, stream);
+}
+// prec 2: the split instantiation; frags from svae_rowgemm_prep_prec(..., 2).
+extern "C" int svae_rowgemm_ld_prec(const float* x, int ldx, const void* frags, const float* bias, float* y, int R,
+                                    int which, int prec, void* stream) {
+    SV_CHECK_ARG(prec == 1 || prec == 2, "svae_rowgemm: prec %d (1 = bf16, 2 = split bf16)", prec);
     SV_CHECK_ARG(x && frags && y && R > 0 && (which == 0 || which == 1), "svae_rowgemm: bad arguments");
     SV_CHECK_ARG(ldx >= (which == 0 ? SV_E : SV_G) && (ldx % 4) == 0, "svae_rowgemm: bad row stride %d", ldx);
     SV_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
                  "svae_rowgemm: operands must be 16-byte aligned");
-    RgArgs a{x, (const unsigned short*)frags, bias, y, R, 0, ldx};
+    RgArgs a{x, (const unsigned short*)frags, bias, y, R, 0, ldx, (const unsigned short*)frags + SV_G * SV_E};
+    if (prec == 2)
+        return which == 0 ? rg_launch<0, false, true>(a, (hipStream_t)stream) : rg_launch<1, false, true>(a, (hipStream_t)stream);
     return which == 0 ? rg_launch<0, false>(a, (hipStream_t)stream) : rg_launch<1, false>(a, (hipStream_t)stream);
 }
 
@@ -239,6 +285,6 @@ extern "C" int svae_rowgemm_ld(const float* x, int ldx, const void* frags, const
 extern "C" int svae_rowgemm_bf16x(const void* x, int ldx, const void* frags, float* y, int R, void* stream) {
     SV_CHECK_ARG(x && frags && y && R > 0 && ldx >= SV_G && (ldx % 8) == 0, "svae_rowgemm_bf16x: bad arguments");
     SV_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "svae_rowgemm_bf16x: operands must be 16-byte aligned");
-    RgArgs a{(const float*)x, (const unsigned short*)frags, nullptr, y, R, 0, ldx};
+    RgArgs a{(const float*)x, (const unsigned short*)frags, nullptr, y, R, 0, ldx, nullptr};
     return rg_launch<1, true>(a, (hipStream_t)stream);
 }

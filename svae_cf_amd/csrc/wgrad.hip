@@ -36,8 +36,26 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
 
 // ABF: dY holds bf16 elements (the GRU's merged gradient array): its tile is 16 rows x 128 columns x 2 B = 4 KiB, one
 // LDS-DMA piece (4 rows) per wave, and a fragment is built from 2-byte reads without conversion.
-template <bool ABF>
+// hi / lo parts of 8 fp32 values as two bf16 fragments: hi = RNE(v), lo = RNE(v - hi); hi + lo carries 16 significant
+// bits of v.  The split instantiation (SPLIT) contracts hi*hi + hi*lo + lo*hi: fp32-class products on the bf16 pipe.
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    uint4 h, l;
+    h.x = pk2(v[0], v[1]); h.y = pk2(v[2], v[3]); h.z = pk2(v[4], v[5]); h.w = pk2(v[6], v[7]);
+    const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+    unsigned lw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        lw[i] = pk2(v[2 * i] - __uint_as_float(hw[i] << 16), v[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u));
+    l.x = lw[0]; l.y = lw[1]; l.z = lw[2]; l.w = lw[3];
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// SPLIT (fp32 dY only): the parity instantiation -- same staging, tiling and slab order, every product carried as
+// hi*hi + hi*lo + lo*hi of bf16 hi/lo operand parts.
+template <bool ABF, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    static_assert(!(ABF && SPLIT), "the split instantiation reads fp32 operands");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             for (int k = 0; k < WK; ++k) cs += ABF ? sv_bf2f(sAh[k * WM + tid]) : sA[k * WM + tid];
         }
         // fragment of a 32-column group: lane (li, lh) takes rows 8 lh .. 8 lh + 7 of column base + li
-        bf16x8 fa[2], fb[2];
+        bf16x8 fa[2], fb[2], fal[2], fbl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             uint4 u;
@@ -125,26 +143,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                 const unsigned short* p = sAh + (8 * lh) * WM + wm + 32 * i + li;
                 u.x = (unsigned)p[0] | ((unsigned)p[WM] << 16); u.y = (unsigned)p[2 * WM] | ((unsigned)p[3 * WM] << 16);
                 u.z = (unsigned)p[4 * WM] | ((unsigned)p[5 * WM] << 16); u.w = (unsigned)p[6 * WM] | ((unsigned)p[7 * WM] << 16);
+                fa[i] = __builtin_bit_cast(bf16x8, u);
+            } else if (SPLIT) {
+                const float* p = sA + (8 * lh) * WM + wm + 32 * i + li;
+                const float v[8] = {p[0], p[WM], p[2 * WM], p[3 * WM], p[4 * WM], p[5 * WM], p[6 * WM], p[7 * WM]};
+                split8(v, fa[i], fal[i]);
             } else {
                 const float* p = sA + (8 * lh) * WM + wm + 32 * i + li;
                 u.x = pk2(p[0], p[WM]); u.y = pk2(p[2 * WM], p[3 * WM]);
                 u.z = pk2(p[4 * WM], p[5 * WM]); u.w = pk2(p[6 * WM], p[7 * WM]);
+                fa[i] = __builtin_bit_cast(bf16x8, u);
             }
-            fa[i] = __builtin_bit_cast(bf16x8, u);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float* p = sB + (8 * lh) * WN + wn + 32 * j + li;
-            uint4 u;
-            u.x = pk2(p[0], p[WN]); u.y = pk2(p[2 * WN], p[3 * WN]);
-            u.z = pk2(p[4 * WN], p[5 * WN]); u.w = pk2(p[6 * WN], p[7 * WN]);
-            fb[j] = __builtin_bit_cast(bf16x8, u);
+            if (SPLIT) {
+                const float v[8] = {p[0], p[WN], p[2 * WN], p[3 * WN], p[4 * WN], p[5 * WN], p[6 * WN], p[7 * WN]};
+                split8(v, fb[j], fbl[j]);
+            } else {
+                uint4 u;
+                u.x = pk2(p[0], p[WN]); u.y = pk2(p[2 * WN], p[3 * WN]);
+                u.z = pk2(p[4 * WN], p[5 * WN]); u.w = pk2(p[6 * WN], p[7 * WN]);
+                fb[j] = __builtin_bit_cast(bf16x8, u);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                if (SPLIT) {       // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fbl[j], acc[i][j], 0, 0, 0);
+                }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
     }
 #undef SV_WG_STAGE
 
@@ -183,6 +216,14 @@ extern "C" int svae_wgrad(const float* dy, const float* x, float* out, float* co
 // recurrent-weight gradient takes (dr, dz, dn*r) out of the merged [R][896] array (remap_from 448, remap_add 224).
 static int wgrad_launch(const void* dy, int dy_bf16, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
                         int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream);
+// prec 1: bf16 operands (svae_wgrad_cols); prec 2: the split instantiation (hi/lo bf16 parts, fp32-class products)
+extern "C" int svae_wgrad_cols_prec(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K,
+                                    int ldy, int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add,
+                                    int prec, void* stream) {
+    SV_CHECK_ARG(prec == 1 || prec == 2, "svae_wgrad_cols_prec: prec %d (1 = bf16, 2 = split bf16)", prec);
+    return wgrad_launch(dy, prec == 2 ? 2 : 0, x, out, colsum, R, N, K, ldy, ldx, nsplit, slab_stride, remap_from,
+                        remap_add, stream);
+}
 extern "C" int svae_wgrad_cols(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
                                int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream) {
     return wgrad_launch(dy, 0, x, out, colsum, R, N, K, ldy, ldx, nsplit, slab_stride, remap_from, remap_add, stream);
@@ -218,10 +259,15 @@ static int wgrad_launch(const void* dy_, int dy_bf16, const float* x, float* out
         hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)wgrad_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
         if (e != hipSuccess) return svae_fail((int)e, "svae_wgrad: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    if (dy_bf16)
+    if (dy_bf16 == 2)
+        hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
+                           (hipStream_t)stream, a);
+    else if (dy_bf16)
         hipLaunchKernelGGL(wgrad_kernel<true>, dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
                            (hipStream_t)stream, a);
     else

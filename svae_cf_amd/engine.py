@@ -128,6 +128,7 @@ class SVAEEngine:
         self.event_pool = []
         self.timer_pool = []
         self.prof = None               # dict tag -> list of (start, end) torch.cuda.Event pairs
+        self.generation = 0            # counts forwards: the workspace holds the activations of the LAST one only
 
     # ------------------------------------------------------------------ parameters
     def P(self, name):
@@ -329,6 +330,7 @@ class SVAEEngine:
         """
         if not self._in_step:
             self._settle()
+        self.generation += 1
         cur = torch.cuda.current_stream()
         with _Launch(cur):
             return self._forward(cur, plan, anneal, eps, seed, step, want_grad, want_loss, defer_loss)

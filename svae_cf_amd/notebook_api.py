@@ -31,7 +31,9 @@ def reference_init(total_items, hyper_params, seed=None):
     """Parameter init with the reference's distributions (nb:690, 703-704, 730 xavier-normal Linear
     weights; torch defaults elsewhere: Linear bias U(+-1/sqrt(fan_in)), Embedding N(0,1), GRU
     U(+-1/sqrt(H)))."""
-    gen = torch.Generator().manual_seed(int(seed) if seed is not None else torch.seed() % (2 ** 31))
+    # seed None: draw from torch's GLOBAL generator, as the reference's Model.__init__ does (reproducible under a
+    # preceding torch.manual_seed, and the caller's RNG state is advanced, not replaced)
+    gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
     E, H = hyper_params["item_embed_size"], hyper_params["rnn_size"]
     D, Lz = hyper_params["hidden_size"], hyper_params["latent_size"]
     I = total_items
@@ -90,11 +92,20 @@ class _ForwardFn(torch.autograd.Function):
         dec = eng.dense_logits()[:, :eng.I].clone()
         mu, ls = eng.mu_logsigma(R)
         ctx.model, ctx.plan = model, plan
+        # the engine keeps ONE set of activations (its workspace): backward is only valid for the forward that
+        # wrote them.  Stamp this forward; backward refuses if another forward ran in between.
+        ctx.generation = eng.generation
         return dec.view(1, R, eng.I), mu.clone(), ls.clone()
 
     @staticmethod
     def backward(ctx, d_dec, d_mu, d_ls):
         eng, plan = ctx.model.engine, ctx.plan
+        if eng.generation != ctx.generation:
+            raise RuntimeError(
+                "Model.forward was called again (or the engine ran another batch) before this backward: the engine "
+                "keeps the activations of its LAST forward only, and gradients are written, not accumulated -- one "
+                "model(x) per loss.backward() (the notebook's train loop, nb:1201-1206); two forwards before a "
+                "backward, or gradient accumulation over several calls, are not supported on this surface")
         eng.backward_dense(plan, d_dec.reshape(plan.R, eng.I), d_mu, d_ls)
         flat = ctx.model.flat
         return eng.grads, None, None, None
@@ -379,6 +390,12 @@ def anneal_for_batch(b, total_anneal_steps=200000, cap=0.2):
     return min(cap, float(b - 2) / total_anneal_steps) if total_anneal_steps > 0 else cap
 
 
+def format_batch_log(epoch, batch, batch_limit, ms_per_batch, loss):
+    """The running-loss line of train() (format string of nb:1226)."""
+    return "| epoch {:3d} | {:5d}/{:5d} batches | ms/batch {:5.2f} | loss {:5.4f}".format(
+        epoch, batch, batch_limit, ms_per_batch, loss)
+
+
 def train(reader, model, optimizer, criterion, hyper_params, epoch=1, log=print):
     """The notebook's train(reader) (nb:1182-1233) with its globals as arguments; same log line."""
     model.train()
@@ -402,65 +419,120 @@ def train(reader, model, optimizer, criterion, hyper_params, epoch=1, log=print)
             if div <= 0:
                 div = 1
             cur = float(torch.stack(losses).sum()) / div
-            log("| epoch {:3d} | {:5d}/{:5d} batches | ms/batch {:5.2f} | loss {:5.4f}".format(
-                epoch, batch, batch_limit, (time.time() - start_time) * 1000 / div, cur))
+            log(format_batch_log(epoch, batch, batch_limit, (time.time() - start_time) * 1000 / div, cur))
             losses, start_time = [], time.time()
     return batch
 
 
+def users_anneal(users_before, total_anneal_steps=200000, cap=0.2):
+    """Anneal the reference applies to the user that follows `users_before` users of the epoch (its schedule
+    advances once per USER: batch_size is 1, nb:80, nb:1211-1215)."""
+    return anneal_for_batch(users_before + 1, total_anneal_steps, cap)
+
+
 def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, log=None, grad_sync=None,
-                  rank=0, world=1):
-    """One epoch with B users per step (length-bucketed, user-sharded over ranks).  The anneal schedule
-    counts optimizer steps exactly as the notebook counts batches."""
+                  rank=0, world=1, anneal_by="users"):
+    """One epoch with B users per step (length-bucketed, user-sharded over ranks).
+
+    KL anneal: the reference's schedule advances once per user (one user = one optimizer step there).  With
+    B*world users per optimizer step the default ``anneal_by="users"`` keeps the KL weight a function of the USERS
+    consumed so far in the epoch -- step b uses the weight the reference gives the first user of that global batch,
+    ``anneal_for_batch(1 + (b-1)*B*world)`` -- so a pass over the data sees the same KL weights as the notebook's
+    pass (up to 0.022 on ML-1M, the 0.2 cap on ML-20M).  ``anneal_by="steps"`` counts optimizer steps instead (B*world
+    times smaller weights over the same pass; the behaviour of round 1).  Either way the batched objective is the
+    MEAN over the batch's users of the reference's per-user loss at that weight, and one Adam step is taken per
+    batch, not per user ("batched objective")."""
     from .dist import rank_batches
+    if anneal_by not in ("users", "steps"):
+        raise ValueError("anneal_by must be 'users' or 'steps'")
     eng = model.engine
     rng = np.random.default_rng(seed + 1000 * epoch)
     lens = [len(u) for u in reader.data]
     batches = rank_batches(lens, batch_size, rng, rank, world)
     eng.grad_sync = grad_sync
     k = reader._k()
+    users_before = 0
     for b, idx in enumerate(batches, start=1):
         plan = build_plan([np.asarray(reader.data[i]) for i in idx], k, user_keys=idx, device=eng.device,
                           total_items=eng.I)
         eng.prepare(plan)
-        eng.train_step(plan, anneal_for_batch(b), seed=seed + epoch)
+        anneal = users_anneal(users_before) if anneal_by == "users" else anneal_for_batch(b)
+        eng.train_step(plan, anneal, seed=seed + epoch)
+        users_before += len(idx) * world
         if log is not None and b % max(1, hyper_params["batch_log_interval"] // batch_size) == 0:
             log("| epoch {:3d} | {:5d}/{:5d} batches | loss {:5.4f}".format(epoch, b, len(batches), float(eng.loss_out[0])))
     return len(batches)
 
 
-def _metrics_from_rankings(rec, held_lists, n_inputs, Ks=(10, 100)):
-    """Loop body nb:633-654 on precomputed descending rankings (rec[u] = top-max(Ks) item ids)."""
-    sums = {}
+# 1 / log2(r) for r = 2 .. : the discount of a hit at 0-based rank r - 2, and the running ideal DCG.  Built with the
+# same scalar calls the reference makes (nb:640, nb:644) and accumulated in the same order, so the vectorised metric
+# arithmetic below is float-identical to its Python loop.
+_KMAX = 100
+_INV_LOG2 = np.array([0.0, 0.0] + [1.0 / float(np.log2(float(r))) for r in range(2, _KMAX + 2)])
+_IDEAL = np.zeros(_KMAX + 1)
+for _j in range(1, _KMAX + 1):
+    _IDEAL[_j] = _IDEAL[_j - 1] + _INV_LOG2[_j + 1]
+
+
+def _user_metrics(rec, held_lists, Ks=(10, 100)):
+    """Per-user NDCG / Rec / Prec @K from descending rankings: rec [U, max(Ks)] item ids (distinct within a row),
+    held_lists[u] = the user's held-out items.  Semantics of the reference's loop (nb:633-648): every held-out item
+    found among the first K recommendations is a hit discounted by 1/log2(rank+2); the ideal DCG covers the first
+    min(n_held, K) positions; Rec divides by the full held-out count, Prec by K.
+    All users at once: one [held entries x max(Ks)] comparison finds each held-out item's rank, ``np.bincount`` with
+    weights sums a user's hits and discounts in held-out order (the same float64 additions, in the same order, as
+    the reference's accumulation).  Returns {"NDCG@10": [U] float64, ...}."""
+    rec = np.asarray(rec)
+    U = len(held_lists)
+    if max(Ks) > _KMAX or rec.shape[1] < max(Ks):
+        raise ValueError("rankings must hold max(Ks) <= %d columns" % _KMAX)
+    n_held = np.fromiter((len(h) for h in held_lists), dtype=np.int64, count=U)
+    if (n_held == 0).any():
+        raise ZeroDivisionError("a user without held-out items (the reference divides by zero there too, nb:646)")
+    flat = np.concatenate([np.asarray(h, dtype=np.int64) for h in held_lists])
+    owner = np.repeat(np.arange(U), n_held)
+    match = rec[owner].astype(np.int64) == flat[:, None]                 # [N, kmax]
+    found = match.any(axis=1)
+    rank = match.argmax(axis=1)                                           # 0-based position in the ranking
+    out = {}
     for k in Ks:
-        for nm in ("NDCG", "Rec", "Prec"):
-            sums["%s@%d" % (nm, k)] = 0.0
+        hit = found & (rank < k)
+        hits = np.bincount(owner, weights=hit.astype(np.float64), minlength=U)
+        dcg = np.bincount(owner, weights=np.where(hit, _INV_LOG2[rank + 2], 0.0), minlength=U)
+        best = _IDEAL[np.minimum(n_held, k)]
+        out["NDCG@%d" % k] = dcg / best
+        out["Rec@%d" % k] = hits / n_held.astype(np.float64)
+        out["Prec@%d" % k] = hits / float(k)
+    return out
+
+
+def _running_sum(total, values):
+    """total + values[0] + values[1] + ... added left to right (np.sum adds pairwise: other last bits)."""
+    return float(np.cumsum(np.concatenate(([total], np.asarray(values, dtype=np.float64))))[-1])
+
+
+def _metrics_from_rankings(rec, held_lists, n_inputs, Ks=(10, 100)):
+    """Sums over users of the six metrics, and len_to_ndcg_at_100_map keyed by n_held + n_inputs + 1 (nb:649-654)."""
+    per = _user_metrics(rec, held_lists, Ks)
+    sums = {key: _running_sum(0.0, v) for key, v in per.items()}
     len_map = {}
-    for u, held in enumerate(held_lists):
-        for k in Ks:
-            rec_list = list(rec[u][:k])
-            best, now_at, dcg, hits = 0.0, 0.0, 0.0, 0.0
-            for movie in held:
-                now_at += 1.0
-                if now_at <= k:
-                    best += 1.0 / float(np.log2(now_at + 1))
-                if movie not in rec_list:
-                    continue
-                hits += 1.0
-                dcg += 1.0 / float(np.log2(float(rec_list.index(movie) + 2)))
-            sums["NDCG@%d" % k] += float(dcg) / float(best)
-            sums["Rec@%d" % k] += float(hits) / float(len(held))
-            sums["Prec@%d" % k] += float(hits) / float(k)
-            if k == 100:
-                len_map.setdefault(int(len(held)) + int(n_inputs[u]) + 1, []).append(float(dcg) / float(best))
+    if 100 in Ks:
+        for u, held in enumerate(held_lists):
+            len_map.setdefault(int(len(held)) + int(n_inputs[u]) + 1, []).append(float(per["NDCG@100"][u]))
     return sums, len_map
 
 
-def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=64, eps_list=None, seed=0):
+def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=64, eps_list=None, seed=0,
+             rank=0, world=1, group=None):
     """nb:594-666.  Returns (metrics dict with the reference's 7 keys, len_to_ndcg_at_100_map).
     Users are scored in batches; the loss is the mean of per-user reference losses at anneal 0.2
     (nb:617), divided by ``batch`` exactly as the reference does (nb:658, one more than the users
-    scored when the train-set early break fired, nb:612-613)."""
+    scored when the train-set early break fired, nb:612-613).
+
+    world > 1 (data parallel, torch.distributed initialised): the user batches are dealt round-robin to the ranks,
+    every rank scores its share, and the per-user metric rows (7 float64 per user) and per-batch loss sums are
+    all-gathered; every rank then adds them up in the single-process order, so the result is bit-identical to a
+    world-size-1 call whatever the number of ranks (noise is keyed by user, not by rank)."""
     eng = model.engine
     pairs = reader.eval_users()
     batch = len(pairs)
@@ -469,8 +541,12 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=64
         batch = len(pairs) + 1
     k = reader._k()
     Ks = (10, 100)
-    loss_sum, sums, len_map = 0.0, None, {}
-    for s in range(0, len(pairs), batch_size):
+    names = ["%s@%d" % (nm, kk) for kk in Ks for nm in ("NDCG", "Rec", "Prec")]
+    mine = {}                        # chunk start -> (loss * users, per-user metric rows [n, 6])
+    starts = list(range(0, len(pairs), batch_size))
+    for ci, s in enumerate(starts):
+        if ci % world != rank:
+            continue
         chunk = pairs[s:s + batch_size]
         plan = build_plan([np.asarray(f) for f, _ in chunk], k, user_keys=np.arange(s, s + len(chunk)),
                           device=eng.device, total_items=eng.I)
@@ -479,32 +555,59 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=64
             from .batch import pack_rows
             eps = torch.from_numpy(pack_rows(plan, eps_list[s:s + len(chunk)], L)).to(eng.device)
         out, idx, _, _ = eng.score(plan, max(Ks), eps=eps, seed=seed, step=s)
-        loss_sum += float(out[0]) * len(chunk)             # engine loss = mean over the chunk's users
         idx = idx.cpu().numpy()
         inv = np.empty(len(chunk), dtype=np.int64)
         inv[plan.order] = np.arange(len(chunk))
-        rec = [idx[inv[u]] for u in range(len(chunk))]
-        cs, lm = _metrics_from_rankings(rec, [h for _, h in chunk], [len(f) - 1 for f, _ in chunk], Ks)
-        sums = cs if sums is None else {kk: sums[kk] + cs[kk] for kk in sums}
-        for kk, v in lm.items():
-            len_map.setdefault(kk, []).extend(v)
+        per = _user_metrics(idx[inv], [h for _, h in chunk], Ks)
+        mine[s] = (float(out[0]) * len(chunk),                 # engine loss = mean over the chunk's users
+                   np.stack([per[n] for n in names], axis=1))
+    if world > 1:
+        import torch.distributed as dist
+        parts = [None] * world
+        dist.all_gather_object(parts, mine, group=group)
+        mine = {}
+        for p_ in parts:
+            mine.update(p_)
+    loss_sum, sums, len_map = 0.0, dict.fromkeys(names, 0.0), {}
+    for s in starts:                                           # the single-process order of additions
+        chunk = pairs[s:s + batch_size]
+        lsum, rows = mine[s]
+        loss_sum += lsum
+        for j, n in enumerate(names):
+            sums[n] = _running_sum(sums[n], rows[:, j])
+        j100 = names.index("NDCG@100")
+        for u, (f, h) in enumerate(chunk):
+            len_map.setdefault(int(len(h)) + (len(f) - 1) + 1, []).append(float(rows[u, j100]))
     total_users = float(len(pairs))
     metrics = {"loss": round(float(loss_sum) / float(batch), 4)}
-    for kk in Ks:
-        for nm in ("NDCG", "Rec", "Prec"):
-            key = "%s@%d" % (nm, kk)
-            metrics[key] = round((100.0 * sums[key]) / total_users, 4)
+    for n in names:
+        metrics[n] = round((100.0 * sums[n]) / total_users, 4)
     return metrics, len_map
 
 
 # --------------------------------------------------------------------------------------------
 # epoch driver (nb:1271-1307, nb:1366-1382): SURVEY 8f row 2
 # --------------------------------------------------------------------------------------------
+_RULE = 89          # width of the notebook's separator rules
+
+
 def _metrics_string(metrics, tag):
-    s = ""
-    for m in metrics:                                     # nb:1283 / nb:1289 / nb:1374
-        s += " | " + m + " = " + str(metrics[m])
-    return s + " (" + tag + ")"
+    """' | name = value' per metric in dict order, then ' (TAG)' (nb:1283-1284, nb:1289-1290, nb:1373-1379)."""
+    return "".join(" | %s = %s" % (m, metrics[m]) for m in metrics) + " (" + tag + ")"
+
+
+def format_epoch_end(epoch, seconds, train_metrics, val_metrics):
+    """The block the driver logs after every epoch (nb:1292-1301): rule, TRAIN line, rule, VAL line, rule."""
+    rule = "-" * _RULE
+    head = "| end of epoch {:3d} | time: {:5.2f}s".format(epoch, seconds)
+    return "\n".join([rule, head + _metrics_string(train_metrics, "TRAIN"), rule,
+                      head + _metrics_string(val_metrics, "VAL"), rule])
+
+
+def format_end_of_training(test_metrics):
+    """The final block (nb:1376-1381)."""
+    rule = "=" * _RULE
+    return "\n".join([rule, "| End of training" + _metrics_string(test_metrics, "TEST"), rule])
 
 
 def fit(model, criterion, train_reader, val_reader, test_reader, hyper_params, optimizer=None, batch_size=None,
@@ -516,44 +619,37 @@ def fit(model, criterion, train_reader, val_reader, test_reader, hyper_params, o
 
     Differences, on purpose: the best model is kept as a ``state_dict`` (reference names and shapes; written to
     ``checkpoint_path`` with torch.save when given) instead of a pickled module (nb:1304); ``batch_size`` switches
-    the per-epoch training from the notebook's per-user ``train`` to ``train_batched``.
+    the per-epoch training from the notebook's per-user ``train`` to ``train_batched``.  Data parallel (world > 1):
+    training and the three evaluations are sharded over the ranks (identical results on every rank); only rank 0
+    logs and writes the checkpoint (to a temporary file, then os.replace: no reader ever sees a partial file).
     Returns (test metrics, len_to_ndcg_at_100_map, best validation NDCG@100)."""
+    import os
     if optimizer is None:             # nb:1252-1267; it also configures the engine's step for train_batched
         optimizer = make_optimizer(model, hyper_params)
+    if world > 1 and batch_size is None:
+        raise ValueError("data parallel training needs batch_size (train_batched); the per-user train() is single-process")
+    say = log if rank == 0 else (lambda *_: None)
+    ev = dict(rank=rank, world=world)
     best_val_ndcg, best_state = None, None
     for epoch in range(1, hyper_params["epochs"] + 1):
         epoch_start_time = time.time()
         if batch_size is None:
-            train(train_reader, model, optimizer, criterion, hyper_params, epoch, log=log)
+            train(train_reader, model, optimizer, criterion, hyper_params, epoch, log=say)
         else:
-            train_batched(train_reader, model, hyper_params, batch_size=batch_size, epoch=epoch, seed=seed, log=log,
+            train_batched(train_reader, model, hyper_params, batch_size=batch_size, epoch=epoch, seed=seed, log=say,
                           grad_sync=grad_sync, rank=rank, world=world)
-        metrics, _ = evaluate(model, criterion, train_reader, hyper_params, True)
-        string = _metrics_string(metrics, "TRAIN")
-        metrics, _ = evaluate(model, criterion, val_reader, hyper_params, False)
-        string2 = _metrics_string(metrics, "VAL")
-        ss = "-" * 89
-        ss += "\n| end of epoch {:3d} | time: {:5.2f}s".format(epoch, (time.time() - epoch_start_time))
-        ss += string
-        ss += "\n"
-        ss += "-" * 89
-        ss += "\n| end of epoch {:3d} | time: {:5.2f}s".format(epoch, (time.time() - epoch_start_time))
-        ss += string2
-        ss += "\n"
-        ss += "-" * 89
-        log(ss)
+        train_metrics, _ = evaluate(model, criterion, train_reader, hyper_params, True, **ev)
+        metrics, _ = evaluate(model, criterion, val_reader, hyper_params, False, **ev)
+        say(format_epoch_end(epoch, time.time() - epoch_start_time, train_metrics, metrics))
         if not best_val_ndcg or metrics["NDCG@100"] >= best_val_ndcg:          # nb:1303
             best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-            if checkpoint_path is not None:
-                torch.save(best_state, checkpoint_path)
+            if checkpoint_path is not None and rank == 0:
+                tmp = "%s.tmp.%d" % (checkpoint_path, os.getpid())
+                torch.save(best_state, tmp)
+                os.replace(tmp, checkpoint_path)
             best_val_ndcg = metrics["NDCG@100"]
     if best_state is not None:
         model.load_state_dict(best_state)                                       # nb:1367
-    metrics, len_to_ndcg_at_100_map = evaluate(model, criterion, test_reader, hyper_params, False)
-    ss = "=" * 89
-    ss += "\n| End of training"
-    ss += _metrics_string(metrics, "TEST")
-    ss += "\n"
-    ss += "=" * 89
-    log(ss)
+    metrics, len_to_ndcg_at_100_map = evaluate(model, criterion, test_reader, hyper_params, False, **ev)
+    say(format_end_of_training(metrics))
     return metrics, len_to_ndcg_at_100_map, best_val_ndcg

@@ -106,3 +106,68 @@ def test_two_ranks_equal_union_batch(prec, opt):
     for k, v in ref_sd.items():
         d = np.linalg.norm(sd[k].astype(np.float64) - v) / np.linalg.norm(v)
         assert d <= 1e-4, (k, d)
+
+
+# ---------------------------------------------------------------------------------------------
+# sharded evaluate(): users dealt to the ranks, per-user metric rows gathered -> the single-process result
+# ---------------------------------------------------------------------------------------------
+def _eval_setup():
+    from svae_cf_amd import notebook_api as N
+    from svae_cf_amd import synth
+    hp = {"history_split_test": [0.8, 0.2], "weight_decay": 5e-3, "batch_size": 1, "item_embed_size": 256,
+          "rnn_size": 200, "hidden_size": 150, "latent_size": 64, "loss_type": "next_k", "next_k": 4,
+          "number_users_to_keep": 10 ** 9, "batch_log_interval": 10 ** 9, "train_cp_users": 20, "total_items": I}
+    users = synth.make_users(70, I, 2.8, 0.6, 60, seed=9)
+    lines = lambda us: ["%d,%d,1\n" % (u, int(it)) for u, items in enumerate(us) for it in items]
+    fold = [u[:int(0.8 * len(u))] for u in users[:37]]
+    held = [u[int(0.8 * len(u)):] for u in users[:37]]
+    val_reader = N.DataReader(hp, lines(fold), lines(held), I, False)
+    train_reader = N.DataReader(hp, lines(users[37:]), None, I, True)
+    model = N.Model(hp, seed=4)
+    return N, hp, model, val_reader, train_reader
+
+
+def _eval_run(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import faulthandler
+    faulthandler.dump_traceback_later(70, exit=True)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, hp, model, val_reader, train_reader = _eval_setup()
+    crit = N.VAELoss(hp, model)
+    out = [N.evaluate(model, crit, val_reader, hp, False, batch_size=8, seed=3, rank=rank, world=world),
+           N.evaluate(model, crit, train_reader, hp, True, batch_size=8, seed=3, rank=rank, world=world)]
+    if world > 1:
+        dist.destroy_process_group()
+    if q is None:
+        return out
+    q.put((rank, out))
+
+
+def test_sharded_evaluate_equals_single_process():
+    """evaluate(..., rank, world) on 2 ranks (5 and 3 user batches dealt round-robin; the train-set early break
+    included): every rank returns the metric dict and len_to_ndcg_at_100_map of the single-process call, exactly."""
+    import torch.multiprocessing as mp
+    ref = _eval_run(0, 1, 0, None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_eval_run, args=(r, WORLD, port, q), daemon=True) for r in range(WORLD)]
+    for p in ps:
+        p.start()
+    try:
+        got = dict(q.get(timeout=100) for _ in ps)
+        for p in ps:
+            p.join(30)
+            assert p.exitcode == 0
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.kill()
+    for r in range(WORLD):
+        for (m, lm), (m0, lm0) in zip(got[r], ref):
+            assert m == m0, (r, m, m0)
+            assert lm == lm0
+    assert ref[0][0]["NDCG@100"] > 0 and ref[1][0]["loss"] > 0

@@ -152,3 +152,29 @@ def test_fit_epoch_driver_log_lines_and_best_checkpoint(tmp_path, batch_size):
     for k in sd:                      # the best model was restored before the test evaluation
         assert torch.equal(sd[k].cpu(), now[k].cpu()), k
     assert all(np.isfinite(v) for v in metrics.values()) and sum(len(v) for v in len_map.values()) == len(te)
+
+
+def test_model_init_reproducible_under_manual_seed_and_stale_backward_is_refused():
+    """Model(hp) draws its parameters from torch's global generator (like the reference's Model.__init__), and the
+    autograd bridge refuses a backward whose forward is no longer the engine's last one (the engine keeps one set of
+    activations; the reference's autograd would keep both)."""
+    from svae_cf_amd import notebook_api as N
+    hp = _hp(60)
+    torch.manual_seed(7)
+    a = N.Model(hp).state_dict()
+    torch.manual_seed(7)
+    model = N.Model(hp)
+    b = model.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    crit = N.VAELoss(hp, model)
+    x1 = torch.tensor([[1, 2, 3, 4, 5]])
+    x2 = torch.tensor([[7, 8, 9]])
+    tg = lambda x: N.SparseTargets(np.concatenate([x[0, 1:].numpy(), [0]]).astype(np.int32)[:, None], 60)
+    d1, m1, l1 = model(x1)
+    loss1 = crit(d1, m1, l1, tg(x1), 0.1)
+    d2, m2, l2 = model(x2)                       # a second forward before the first backward
+    loss2 = crit(d2, m2, l2, tg(x2), 0.1)
+    with pytest.raises(RuntimeError, match="LAST forward"):
+        loss1.backward()
+    loss2.backward()                             # the last forward's backward is fine
+    assert torch.isfinite(model.engine.grads).all()

@@ -387,3 +387,78 @@ def test_masked_topk_equals_stable_descending_sort_on_edge_cases():
     small = torch.randn(3, 50, generator=g)
     run(small, [[], [1], [2, 3]], 50)
     run(torch.randn(2, 3000, generator=g), [[], []], 2000)             # K above the LDS sort: arg-max rounds
+
+
+def test_postfix_targets_beyond_256_per_row_vs_oracle():
+    """loss_type 'postfix' (nb:515-519): row t targets EVERY later item, so a 300-item user has rows with up to 299
+    targets -- more than one target per thread of the row kernel.  fp32 path (svae_softmax_nll over dense logits,
+    the notebook surface's path) against the fp64 oracle: loss 1e-5, gradients 1e-4; bf16 fused path: loss 1e-3."""
+    import svae_cf_amd as S
+    rs = np.random.RandomState(21)
+    I = 400
+    users = [rs.permutation(I)[:300], rs.permutation(I)[:9], rs.permutation(I)[:270]]
+    epsl = [rs.standard_normal((len(u) - 1, 64)).astype(np.float32) for u in users]
+    p = O.make_params(I, 31)
+    K = 10 ** 9
+    loss_ref, grads_ref = O.batch_loss_and_grads(p, users, epsl, 0.07, K, np.float64)
+    eng = _engine(I)
+    eng.load_state_dict(_sd(p))
+    plan = S.build_plan(users, K, device="cuda", total_items=I)
+    assert plan.K == 299
+    eps = torch.from_numpy(S.pack_rows(plan, epsl, 64)).cuda()
+    out = eng.forward(plan, 0.07, eps=eps)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(float(out[0]) - loss_ref) <= 1e-5 * abs(loss_ref)
+    gd = eng.grad_dict()
+    for k in O.PARAM_NAMES:
+        assert _l2(gd[k].cpu().numpy(), grads_ref[k]) <= 1e-4, k
+    eng16 = _engine(I, prec=1)
+    eng16.load_state_dict(_sd(p))
+    out16 = eng16.forward(plan, 0.07, eps=eps)
+    eng16.backward()
+    torch.cuda.synchronize()
+    assert abs(float(out16[0]) - loss_ref) <= 1e-3 * abs(loss_ref)
+    gd = eng16.grad_dict()
+    for k in O.PARAM_NAMES:
+        assert _l2(gd[k].cpu().numpy(), grads_ref[k]) <= 3e-2, k
+
+
+def test_philox_normal_stream_properties():
+    """svae_philox_normal (the counter-based replacement of np.random.normal, nb:744) through the C-ABI:
+    same (seed, step, key) -> same bits on every launch and wherever the row sits in the batch (shard invariance);
+    another step or seed -> another stream; 10^6 draws look N(0,1) (mean, variance, 4th moment, tail fractions);
+    rows with adjacent keys and adjacent columns are uncorrelated."""
+    from svae_cf_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    R = 15625                                   # x 64 columns = 10^6 draws
+    keys = (torch.arange(R, dtype=torch.int64) // 50 << 20) + torch.arange(R, dtype=torch.int64) % 50   # (user << 20) + t
+    keys = keys.cuda()
+
+    def draw(k, seed, step):
+        out = torch.empty(k.numel(), 64, device="cuda")
+        _lib.call("svae_philox_normal", out.data_ptr(), k.data_ptr(), k.numel(), seed, step, st)
+        torch.cuda.synchronize()
+        return out
+    a = draw(keys, 1234, 7)
+    assert torch.equal(a, draw(keys, 1234, 7))
+    perm = torch.randperm(R, generator=torch.Generator().manual_seed(0)).cuda()
+    assert torch.equal(draw(keys[perm], 1234, 7), a[perm])             # a row's noise depends on its key only
+    assert torch.equal(draw(keys[100:300], 1234, 7), a[100:300])
+    b, c = draw(keys, 1234, 8), draw(keys, 1235, 7)
+    assert not torch.equal(a, b) and not torch.equal(a, c)
+    x = a.double().cpu().numpy()
+    n = x.size
+    assert np.isfinite(x).all()
+    assert abs(x.mean()) < 5 / np.sqrt(n)                               # 5 sigma of the mean
+    assert abs(x.var() - 1.0) < 5 * np.sqrt(2.0 / n)
+    assert abs((x ** 4).mean() - 3.0) < 5 * np.sqrt(96.0 / n)
+    for t, pr in ((1.0, 0.31731), (2.0, 0.04550), (3.0, 0.002700), (4.0, 6.334e-5)):
+        frac = (np.abs(x) > t).mean()
+        assert abs(frac - pr) < 5 * np.sqrt(pr * (1 - pr) / n) + 1e-6, (t, frac)
+    corr = lambda u, v: float(np.mean(u * v))
+    assert abs(corr(x[:-1], x[1:])) < 5 / np.sqrt(n)                    # adjacent keys (t, t + 1), same column
+    assert abs(corr(x[:, :-1], x[:, 1:])) < 5 / np.sqrt(n)              # adjacent columns (same Philox block or next)
+    assert abs(corr(x[:, 0::4], x[:, 1::4])) < 5 / np.sqrt(n / 4)       # the two outputs of one Box-Muller pair
+    y, z = b.double().cpu().numpy(), c.double().cpu().numpy()
+    assert abs(corr(x, y)) < 5 / np.sqrt(n) and abs(corr(x, z)) < 5 / np.sqrt(n)

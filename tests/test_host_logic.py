@@ -260,3 +260,117 @@ def test_grad_sync_gloo_world2():
         p.join(60)
     for rank, lo, hi, gs, m in res:
         assert lo == hi == 3.0 and gs == 0.5 and m == [3.0, 20.0]
+
+
+# ---------------------------------------------------------------------------------------------
+# epoch driver's log lines against the reference's OWN printed output
+# ---------------------------------------------------------------------------------------------
+def test_log_lines_byte_identical_to_reference_output(golden_dir):
+    """tests/golden/ref_log_lines.json holds the lines the reference's run printed (embedded cell output nb:882-1175,
+    extracted by oracle/make_golden_logs.py) and the numbers in them; the same numbers through notebook_api's
+    formatters must give the same bytes: 125 running lines (format nb:1226), 25 end-of-epoch blocks (nb:1292-1301),
+    the end-of-training block (nb:1376-1381)."""
+    import json
+    from svae_cf_amd import notebook_api as N
+    with open(os.path.join(golden_dir, "ref_log_lines.json")) as f:
+        g = json.load(f)
+    assert len(g["batch_lines"]) == 125 and len(g["epoch_blocks"]) == 25
+    for b in g["batch_lines"]:
+        assert N.format_batch_log(b["epoch"], b["batch"], b["batch_limit"], b["ms_per_batch"], b["loss"]) == b["line"]
+    keys = ["loss", "NDCG@10", "Rec@10", "Prec@10", "NDCG@100", "Rec@100", "Prec@100"]       # nb:597-603
+    for e in g["epoch_blocks"]:
+        assert [k for k, _ in e["train"]] == keys
+        assert N.format_epoch_end(e["epoch"], e["seconds"], dict(e["train"]), dict(e["val"])) == e["text"]
+    assert N.format_end_of_training(dict(g["end_block"]["test"])) == g["end_block"]["text"]
+
+
+def test_fit_logs_through_the_pinned_formatters(monkeypatch):
+    """fit() and train() emit exactly what the pinned formatters return (no second copy of the format strings)."""
+    import inspect
+    from svae_cf_amd import notebook_api as N
+    src_fit, src_train = inspect.getsource(N.fit), inspect.getsource(N.train)
+    assert "format_epoch_end(" in src_fit and "format_end_of_training(" in src_fit and "{:5.2f}" not in src_fit
+    assert "format_batch_log(" in src_train and "{:5.2f}" not in src_train
+
+
+def test_evaluate_returns_metric_keys_in_reference_order():
+    from svae_cf_amd import notebook_api as N
+    per = N._user_metrics(np.arange(100)[None, :], [[3, 500]])
+    assert list(per) == ["NDCG@10", "Rec@10", "Prec@10", "NDCG@100", "Rec@100", "Prec@100"]
+
+
+# ---------------------------------------------------------------------------------------------
+# vectorised metric arithmetic == the reference's loop, to the last bit
+# ---------------------------------------------------------------------------------------------
+def test_user_metrics_float_identical_to_reference_loop():
+    """notebook_api._user_metrics (all users at once, bincount accumulation) against oracle.user_metrics (the
+    reference's per-user Python loop nb:633-648): exactly equal float64 values -- random catalogues, held-out lists
+    from 1 to 400 items, held-out items repeated, no hit at all, every item a hit."""
+    from oracle import svae_numpy as O
+    from svae_cf_amd import notebook_api as N
+    rs = np.random.RandomState(3)
+    rec, held = [], []
+    for u in range(300):
+        I = int(rs.choice([120, 500, 5000]))
+        rec.append(rs.permutation(I)[:100])
+        n = int(rs.choice([1, 2, 5, 30, 99, 100, 101, 400]))
+        h = rs.randint(0, I, n)                     # with replacement: repeated held-out items occur
+        if u % 7 == 0:
+            h = rec[-1][rs.permutation(100)[:min(n, 100)]]      # all hits
+        if u % 11 == 0:
+            h = np.full(n, I + 5)                   # no hit
+        held.append([int(v) for v in h])
+    per = N._user_metrics(np.stack(rec), held)
+    for u in range(300):
+        ref = O.user_metrics(rec[u], held[u])
+        for k, v in ref.items():
+            assert per[k][u] == v, (u, k, per[k][u], v)
+    sums, len_map = N._metrics_from_rankings(np.stack(rec), held, [7] * 300)
+    for k in sums:
+        acc = 0.0
+        for u in range(300):
+            acc += O.user_metrics(rec[u], held[u])[k]
+        assert sums[k] == acc
+    assert sum(len(v) for v in len_map.values()) == 300
+    with pytest.raises(ZeroDivisionError):
+        N._user_metrics(np.stack(rec[:2]), [[1], []])
+
+
+# ---------------------------------------------------------------------------------------------
+# KL anneal of the batched path counts USERS, as the reference's schedule does
+# ---------------------------------------------------------------------------------------------
+def test_batched_anneal_follows_users_consumed():
+    """The reference advances its KL weight once per user (batch_size 1).  train_batched's default gives step b the
+    weight the reference gives the first user of that global batch; B = 1, world = 1 is the reference schedule."""
+    from svae_cf_amd import notebook_api as N
+    for B, world in ((1, 1), (256, 1), (256, 8)):
+        before = 0
+        for b in range(1, 60):
+            a = N.users_anneal(before)
+            assert a == N.anneal_for_batch(1 + (b - 1) * B * world)
+            if B == 1:
+                assert a == N.anneal_for_batch(b)
+            before += B * world
+    # one pass over ML-1M's 4534 users ends near the reference's last weight (0.0227), not 256x below it
+    assert abs(N.users_anneal(17 * 256) - N.anneal_for_batch(17 * 256 + 1)) == 0.0
+    assert N.users_anneal(17 * 256) > 0.02 and N.anneal_for_batch(18) < 1e-4
+    # ML-20M-sized pass reaches the cap
+    assert N.users_anneal(137000) == 0.2
+
+
+def test_reference_init_draws_from_global_generator():
+    """Model(hyper_params) without a seed must be reproducible under torch.manual_seed, like the reference's
+    Model.__init__ (global generator), and must not reseed the caller's generator."""
+    from svae_cf_amd import notebook_api as N
+    hp = dict(item_embed_size=256, rnn_size=200, hidden_size=150, latent_size=64)
+    torch.manual_seed(123)
+    a = N.reference_init(40, hp)
+    after_a = torch.rand(1)
+    torch.manual_seed(123)
+    b = N.reference_init(40, hp)
+    after_b = torch.rand(1)
+    assert all(torch.equal(a[k], b[k]) for k in a) and torch.equal(after_a, after_b)
+    c = N.reference_init(40, hp)
+    assert not torch.equal(a["item_embed.weight"], c["item_embed.weight"])
+    s1, s2 = N.reference_init(40, hp, seed=5), N.reference_init(40, hp, seed=5)
+    assert all(torch.equal(s1[k], s2[k]) for k in s1)
