@@ -187,6 +187,51 @@ int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int
                          const int* occ_items, int nocc_long, float* slabs, float* gw3, float* gb3,
                          const int* sched, int nwg, int ns_q, int ns_rem, int parts, void* stream);
 
+/* ---- split instantiations ("prec 2") of the fused bf16 kernels ---------------------------------------------
+ * Same reference call sites as the entry points they extend (nb:694-710, nb:759, nb:802-808, nb:1205).  Every bf16
+ * operand is carried as hi + mid + lo parts (mid = RNE(v - hi), lo = RNE(v - hi - mid): all 24 significant bits)
+ * and every product by its six leading terms hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi, so the SAME kernel
+ * templates (tiling, work division, constant columns, running stabiliser, slab / finish structure) deliver
+ * fp32-class results: the parity gates of tests/ run through them.  Six times the MFMA work and a simple one-tile
+ * LDS pipeline in the sweeps: never timed.
+ *   prec argument: 1 = bf16 (identical to the entry point without the suffix), 2 = split.
+ *   part strides (projection copies): the mid and lo parts of a bf16 operand copy sit part_stride and
+ *   2 part_stride ELEMENTS behind it, same shape and layout; one stride for the three row copies (h2b / h2s /
+ *   h2tb), one for the three item copies (w3b / w3s / w3tb); 0 = bf16 copies only.
+ *   fragment buffers (svae_rowgemm_prep_prec, svae_mlp_prep_prec) hold the hi fragments followed by the mid and
+ *   the lo fragments: three times svae_rowgemm_frag_elems / svae_mlp_frag_elems elements when prec == 2. */
+int svae_wgrad_cols_prec(const float* dy, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
+                         int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, int prec,
+                         void* stream);
+int svae_rowgemm_prep_prec(const float* wih, int which, void* frags, int prec, void* stream);
+int svae_rowgemm_ld_prec(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,
+                         int prec, void* stream);
+int svae_mlp_prep_prec(const float* w1, const float* wl, const float* w2, void* frags, int prec, void* stream);
+int svae_mlp_fwd_prec(const float* hs, const float* eps, const void* frags, const float* b1, const float* bl,
+                      const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R, int prec,
+                      void* stream);
+int svae_mlp_bwd_prec(const float* dd1, const float* tmp, const float* eps, const float* enc, const float* w_kl,
+                      const void* frags, float anneal, float* dtmp, float* denc, float* dhs, int R, int prec,
+                      void* stream);
+int svae_proj_prep_rows_range_split(const float* h2, int R, int R_pad, int row0, int row1, void* h2b, void* h2s,
+                                    void* h2tb, long long part_stride, void* stream);
+int svae_proj_prep_items_split(const float* w3, const float* b3, int I, int I_pad, void* w3b, void* w3s, void* w3tb,
+                               long long part_stride, void* stream);
+int svae_proj_nll_fwd_split(const void* h2s, const void* w3b, const float* h2, const float* w3, const float* b3,
+                            const int* tgt, int R, int I, int K, float* part, float* nll_row, float* lse,
+                            const int* sched, int nwg, int ns_q, int ns_rem, long long row_part_stride,
+                            long long item_part_stride, void* stream);
+int svae_proj_nll_fwd_dh_split(const void* h2s, void* h2b, const void* w3b, const void* w3tb, int I_pad,
+                               const float* h2, const float* w3, const float* b3, const int* tgt, const float* w_nll,
+                               int R, int I, int K, float* slabs, float* mpart, float* nll_row, float* lse, float* dd1,
+                               const int* sched, int nwg, int ns_q, int ns_rem, int parts, long long row_part_stride,
+                               long long item_part_stride, void* stream);
+int svae_proj_nll_bwd_dw_split(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad, int I, int I_rows,
+                               const float* h2, const float* w_nll, const int* occ_off, const int* occ_row,
+                               const int* occ_items, int nocc_long, float* slabs, float* gw3, float* gb3,
+                               const int* sched, int nwg, int ns_q, int ns_rem, int parts, long long row_part_stride,
+                               long long item_part_stride, void* stream);
+
 /* Timing hooks (measurement only; no counterpart in the reference): svae_proj_time_next arms the calling thread's next
  * sweep launch with start / stop events (from svae_event_create) attached to the dispatch itself; read the kernel's
  * duration with svae_event_elapsed_ms (synchronises on the stop event). */

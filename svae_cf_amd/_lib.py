@@ -68,10 +68,20 @@ SIGNATURES = {
     "svae_rowgemm_ld": [_P, _I, _P, _P, _P, _I, _I, _P],
     "svae_wgrad_cols": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _LL, _I, _I, _P],
     "svae_zero": [_P, _LL, _P],
-    "svae_proj_nsplit": [],
-    "svae_proj_tile": [],
-    "svae_check_device": [],
-    "svae_abi_version": [],
+    # split instantiations (prec 2) of the fused kernels
+    "svae_wgrad_cols_prec": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _LL, _I, _I, _I, _P],
+    "svae_rowgemm_prep_prec": [_P, _I, _P, _I, _P],
+    "svae_rowgemm_ld_prec": [_P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "svae_mlp_prep_prec": [_P, _P, _P, _P, _I, _P],
+    "svae_mlp_fwd_prec": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "svae_mlp_bwd_prec": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _P],
+    "svae_proj_prep_rows_range_split": [_P, _I, _I, _I, _I, _P, _P, _P, _LL, _P],
+    "svae_proj_prep_items_split": [_P, _P, _I, _I, _P, _P, _P, _LL, _P],
+    "svae_proj_nll_fwd_split": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _LL, _LL, _P],
+    "svae_proj_nll_fwd_dh_split": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I,
+                                   _I, _I, _LL, _LL, _P],
+    "svae_proj_nll_bwd_dw_split": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I,
+                                   _LL, _LL, _P],
 }
 
 _lib = None

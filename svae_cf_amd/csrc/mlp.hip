@@ -42,12 +42,12 @@ __device__ __forceinline__ int kmap_nat(int s, int lh, int j) { return 16 * s + 
 __device__ __forceinline__ int kmap_acc(int s, int lh, int j) { return 16 * s + (j & 3) + 8 * (j >> 2) + 4 * lh; }
 
 __global__ void mlp_prep_kernel(const float* __restrict__ w1, const float* __restrict__ wl,
-                                const float* __restrict__ w2, unsigned short* __restrict__ frags) {
+                                const float* __restrict__ w2, unsigned short* __restrict__ frags, int parts) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = gid >> 6, lane = gid & 63;
     if (f >= NFRAG) return;
     const int li = lane & 31, lh = lane >> 5;
-    unsigned short v[8];
+    unsigned short v[8], vm[8], vl[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float x;
@@ -71,24 +71,60 @@ __global__ void mlp_prep_kernel(const float* __restrict__ w1, const float* __res
             x = w1[(size_t)kmap_acc(s, lh, j) * SV_HP + 32 * nt + li];
         }
         v[j] = sv_f2bf(x);
+        const float r = x - sv_bf2f(v[j]);
+        vm[j] = sv_f2bf(r);
+        vl[j] = sv_f2bf(r - sv_bf2f(vm[j]));
     }
     uint4 u;
     u.x = v[0] | ((unsigned)v[1] << 16); u.y = v[2] | ((unsigned)v[3] << 16);
     u.z = v[4] | ((unsigned)v[5] << 16); u.w = v[6] | ((unsigned)v[7] << 16);
     reinterpret_cast<uint4*>(frags)[(size_t)f * 64 + lane] = u;
+    if (parts == 3) {    // the split instantiation's mid and lo parts: fragments NFRAG + f and 2 NFRAG + f
+        u.x = vm[0] | ((unsigned)vm[1] << 16); u.y = vm[2] | ((unsigned)vm[3] << 16);
+        u.z = vm[4] | ((unsigned)vm[5] << 16); u.w = vm[6] | ((unsigned)vm[7] << 16);
+        reinterpret_cast<uint4*>(frags)[(size_t)(NFRAG + f) * 64 + lane] = u;
+        u.x = vl[0] | ((unsigned)vl[1] << 16); u.y = vl[2] | ((unsigned)vl[3] << 16);
+        u.z = vl[4] | ((unsigned)vl[5] << 16); u.w = vl[6] | ((unsigned)vl[7] << 16);
+        reinterpret_cast<uint4*>(frags)[(size_t)(2 * NFRAG + f) * 64 + lane] = u;
+    }
 }
 
 __device__ __forceinline__ unsigned pk2(float a, float b) {
     const bf16v2 h = __builtin_convertvector((f32x2){a, b}, bf16v2);
     return __builtin_bit_cast(unsigned, h);
 }
+// ---- split instantiation (SPLIT): operands as bf16 hi + mid + lo parts (mid = RNE(v - hi), lo = RNE(v - hi - mid):
+// all 24 significant bits), a product as its six leading terms hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi ->
+// fp32-class results from the same kernels (the parity gates run through it).  Activations are split in registers;
+// the weights' mid / lo fragments are read straight from L2 (the LDS holds the hi fragments); tanh / exp use the
+// accurate library forms.  A B operand is a `B3`: only .h is computed (and alive) in the bf16 instantiation.
+struct B3 { bf16x8 h, m, l; };
+// 8 floats -> parts
+template <bool SPLIT>
+__device__ __forceinline__ void parts8(const float (&v)[8], B3& o) {
+    unsigned hw[4], mw[4], lw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hw[i] = pk2(v[2 * i], v[2 * i + 1]);
+        if (SPLIT) {
+            const float r0 = v[2 * i] - __uint_as_float(hw[i] << 16), r1 = v[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u);
+            mw[i] = pk2(r0, r1);
+            lw[i] = pk2(r0 - __uint_as_float(mw[i] << 16), r1 - __uint_as_float(mw[i] & 0xFFFF0000u));
+        }
+    }
+    o.h = __builtin_bit_cast(bf16x8, (uint4){hw[0], hw[1], hw[2], hw[3]});
+    if (SPLIT) {
+        o.m = __builtin_bit_cast(bf16x8, (uint4){mw[0], mw[1], mw[2], mw[3]});
+        o.l = __builtin_bit_cast(bf16x8, (uint4){lw[0], lw[1], lw[2], lw[3]});
+    }
+}
 // an accumulator tile -> the two B fragments (k-steps 2T, 2T+1) of the next layer
-__device__ __forceinline__ void to_frags(const f32x16& c, bf16x8& f0, bf16x8& f1) {
-    uint4 a, b;
-    a.x = pk2(c[0], c[1]);   a.y = pk2(c[2], c[3]);   a.z = pk2(c[4], c[5]);   a.w = pk2(c[6], c[7]);
-    b.x = pk2(c[8], c[9]);   b.y = pk2(c[10], c[11]); b.z = pk2(c[12], c[13]); b.w = pk2(c[14], c[15]);
-    f0 = __builtin_bit_cast(bf16x8, a);
-    f1 = __builtin_bit_cast(bf16x8, b);
+template <bool SPLIT>
+__device__ __forceinline__ void to_frags(const f32x16& c, B3& f0, B3& f1) {
+    const float a[8] = {c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]};
+    const float b[8] = {c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15]};
+    parts8<SPLIT>(a, f0);
+    parts8<SPLIT>(b, f1);
 }
 // fragment f of the kernel's LDS-resident image (lane-linear 16-byte reads: conflict-free)
 __device__ __forceinline__ bf16x8 frag_ld(const char* lds, int f, int lane) {
@@ -107,12 +143,34 @@ constexpr int NFRAG_FWD = OFF_B1 - OFF_F1;     // 130
 constexpr int NFRAG_BWD = NFRAG - OFF_B1;      // 130
 constexpr int MLP_ROWS = 128;                  // rows per block (4 waves x 32)
 // natural-order B fragment from an fp32 row: 8 consecutive floats
-__device__ __forceinline__ bf16x8 row_frag(const float* p) {
+template <bool SPLIT>
+__device__ __forceinline__ B3 row_frag(const float* p) {
     const float4 lo = *reinterpret_cast<const float4*>(p);
     const float4 hi = *reinterpret_cast<const float4*>(p + 4);
-    uint4 u;
-    u.x = pk2(lo.x, lo.y); u.y = pk2(lo.z, lo.w); u.z = pk2(hi.x, hi.y); u.w = pk2(hi.z, hi.w);
-    return __builtin_bit_cast(bf16x8, u);
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    B3 o;
+    parts8<SPLIT>(v, o);
+    return o;
+}
+// c += W (fragment fl of the LDS image = fragment f of the whole set) x B
+template <bool SPLIT>
+__device__ __forceinline__ void mm(f32x16& c, const char* wlds, int fl, const unsigned short* frags, int f, int lane,
+                                   const B3& b) {
+    const bf16x8 wh = frag_ld(wlds, fl, lane);
+    if (SPLIT) {       // small terms first
+        const bf16x8 wm = *reinterpret_cast<const bf16x8*>(frags + ((size_t)(NFRAG + f) * 64 + lane) * 8);
+        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(frags + ((size_t)(2 * NFRAG + f) * 64 + lane) * 8);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, b.h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, b.l, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, b.m, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, b.h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, b.m, c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, b.h, c, 0, 0, 0);
+}
+template <bool SPLIT> __device__ __forceinline__ float mlp_tanh(float x) { return SPLIT ? tanhf(x) : sv_tanh_fast(x); }
+template <bool SPLIT> __device__ __forceinline__ float mlp_exp(float x) {
+    return SPLIT ? expf(x) : __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
 // accumulator tile initialised with a per-feature bias: register group g holds features 32 nt + 8 g + 4 lh + 0..3
 __device__ __forceinline__ void bias_init(f32x16& c, const float* bias, int nt, int lh) {
@@ -167,8 +225,9 @@ __device__ __forceinline__ void prep_vals(int c, float v, bool live, unsigned sh
     }
 }
 
-template <bool PREP>
+template <bool PREP, bool SPLIT = false>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
+    static_assert(!(PREP && SPLIT), "the split instantiation leaves the operand copies to svae_proj_prep_rows_range_split");
     extern __shared__ __attribute__((aligned(16))) char wlds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -178,24 +237,24 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
     const size_t rc = ok ? r : a.R - 1;          // loads are clamped, stores masked
 
     // ---- encoder: enc^T = tanh(W1 hs^T + b1)
-    bf16x8 hb[KS_H];
+    B3 hb[KS_H];
 #pragma unroll
-    for (int s = 0; s < KS_H; ++s) hb[s] = row_frag(a.hs + rc * SV_HP + 16 * s + 8 * lh);
+    for (int s = 0; s < KS_H; ++s) hb[s] = row_frag<SPLIT>(a.hs + rc * SV_HP + 16 * s + 8 * lh);
     stage_frags(a.frags, OFF_F1, NFRAG_FWD, wlds, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    bf16x8 pe[KS_D];
+    B3 pe[KS_D];
 #pragma unroll
     for (int nt = 0; nt < NT_D; ++nt) {
         f32x16 c;
         bias_init(c, a.b1, nt, lh);
 #pragma unroll
         for (int s = 0; s < KS_H; ++s)
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_F1 + nt * KS_H + s, lane), hb[s], c, 0, 0, 0);
+            mm<SPLIT>(c, wlds, OFF_F1 + nt * KS_H + s, a.frags, OFF_F1 + nt * KS_H + s, lane, hb[s]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) c[i] = sv_tanh_fast(c[i]);
+        for (int i = 0; i < 16; ++i) c[i] = mlp_tanh<SPLIT>(c[i]);
         tile_store(a.enc + rc * SV_DP, nt, lh, c, ok);
-        to_frags(c, pe[2 * nt], pe[2 * nt + 1]);
+        to_frags<SPLIT>(c, pe[2 * nt], pe[2 * nt + 1]);
     }
     // ---- (mu | ls)^T = Wl enc^T + bl
     f32x16 t[NT_L2];
@@ -204,12 +263,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
         bias_init(t[nt], a.bl, nt, lh);
 #pragma unroll
         for (int s = 0; s < KS_D; ++s)
-            t[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_F2 + nt * KS_D + s, lane), pe[s], t[nt], 0, 0, 0);
+            mm<SPLIT>(t[nt], wlds, OFF_F2 + nt * KS_D + s, a.frags, OFF_F2 + nt * KS_D + s, lane, pe[s]);
         tile_store(a.tmp + rc * SV_L2, nt, lh, t[nt], ok);
     }
     // ---- z = mu + exp(ls) eps, KL row term (log_sigma is a log-std for sampling and a log-variance in KL:
     //      reproduced as the reference has it, nb:743 / nb:797)
-    bf16x8 pz[KS_L];
+    B3 pz[KS_L];
     float kl = 0.f;
 #pragma unroll
     for (int q = 0; q < NT_L; ++q) {
@@ -221,13 +280,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float mu = t[q][4 * g + c], ls = t[q + 2][4 * g + c];
-                const float sg = __builtin_amdgcn_exp2f(ls * 1.4426950408889634f);
+                const float sg = mlp_exp<SPLIT>(ls);
                 zt[4 * g + c] = mu + sg * ev[c];
                 kl += 0.5f * (-ls + sg + mu * mu - 1.0f);
             }
         }
         tile_store(a.z + rc * SV_L, q, lh, zt, ok);
-        to_frags(zt, pz[2 * q], pz[2 * q + 1]);
+        to_frags<SPLIT>(zt, pz[2 * q], pz[2 * q + 1]);
     }
     kl += __shfl_xor(kl, 32, 64);
     if (ok && lh == 0) a.kl_row[r] = kl;
@@ -238,9 +297,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
         bias_init(c, a.b2, nt, lh);
 #pragma unroll
         for (int s = 0; s < KS_L; ++s)
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_F3 + nt * KS_L + s, lane), pz[s], c, 0, 0, 0);
+            mm<SPLIT>(c, wlds, OFF_F3 + nt * KS_L + s, a.frags, OFF_F3 + nt * KS_L + s, lane, pz[s]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) c[i] = sv_tanh_fast(c[i]);
+        for (int i = 0; i < 16; ++i) c[i] = mlp_tanh<SPLIT>(c[i]);
         tile_store(a.d1 + rc * SV_DP, nt, lh, c, ok);
         if (PREP && r < a.row1) {
             // the sweeps' operand copies straight from the accumulators (same values as a conversion of the d1 just
@@ -279,6 +338,7 @@ struct MlpBwdArgs {
     int R;
 };
 
+template <bool SPLIT = false>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wlds[];
     const int lane = threadIdx.x & 63;
@@ -289,9 +349,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
     const size_t rc = ok ? r : a.R - 1;
 
     // ---- dz^T = W2^T dd1^T
-    bf16x8 db[KS_D];
+    B3 db[KS_D];
 #pragma unroll
-    for (int s = 0; s < KS_D; ++s) db[s] = row_frag(a.dd1 + rc * SV_DP + 16 * s + 8 * lh);
+    for (int s = 0; s < KS_D; ++s) db[s] = row_frag<SPLIT>(a.dd1 + rc * SV_DP + 16 * s + 8 * lh);
     stage_frags(a.frags, OFF_B1, NFRAG_BWD, wlds, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -302,11 +362,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
         for (int i = 0; i < 16; ++i) dz[nt][i] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS_D; ++s)
-            dz[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, nt * KS_D + s, lane), db[s], dz[nt], 0, 0, 0);
+            mm<SPLIT>(dz[nt], wlds, nt * KS_D + s, a.frags, OFF_B1 + nt * KS_D + s, lane, db[s]);
     }
     // ---- latent backward: dmu = dz + a w mu ;  dls = dz exp(ls) eps + a w 0.5 (exp(ls) - 1)
     const float kw = a.anneal * a.w_kl[rc];
-    bf16x8 pd[KS_L2];
+    B3 pd[KS_L2];
 #pragma unroll
     for (int q = 0; q < NT_L; ++q) {
         f32x16 dmu, dls;
@@ -318,7 +378,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
             const float ev[4] = {e.x, e.y, e.z, e.w}, mv[4] = {m.x, m.y, m.z, m.w}, lv[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float sg = __builtin_amdgcn_exp2f(lv[c] * 1.4426950408889634f);
+                const float sg = mlp_exp<SPLIT>(lv[c]);
                 const float gz = dz[q][4 * g + c];
                 dmu[4 * g + c] = gz + kw * mv[c];
                 dls[4 * g + c] = gz * sg * ev[c] + kw * 0.5f * (sg - 1.0f);
@@ -326,11 +386,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
         }
         tile_store(a.dtmp + rc * SV_L2, q, lh, dmu, ok);
         tile_store(a.dtmp + rc * SV_L2, q + 2, lh, dls, ok);
-        to_frags(dmu, pd[2 * q], pd[2 * q + 1]);
-        to_frags(dls, pd[2 * (q + 2)], pd[2 * (q + 2) + 1]);
+        to_frags<SPLIT>(dmu, pd[2 * q], pd[2 * q + 1]);
+        to_frags<SPLIT>(dls, pd[2 * (q + 2)], pd[2 * (q + 2) + 1]);
     }
     // ---- denc^T = (Wl^T dtmp^T) (1 - enc^2)
-    bf16x8 pn[KS_D];
+    B3 pn[KS_D];
 #pragma unroll
     for (int nt = 0; nt < NT_D; ++nt) {
         f32x16 c;
@@ -338,7 +398,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
         for (int i = 0; i < 16; ++i) c[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS_L2; ++s)
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_B2 - OFF_B1 + nt * KS_L2 + s, lane), pd[s], c, 0, 0, 0);
+            mm<SPLIT>(c, wlds, OFF_B2 - OFF_B1 + nt * KS_L2 + s, a.frags, OFF_B2 + nt * KS_L2 + s, lane, pd[s]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 y = *reinterpret_cast<const float4*>(a.enc + rc * SV_DP + 32 * nt + 8 * g + 4 * lh);
@@ -346,7 +406,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
             c[4 * g + 2] *= 1.0f - y.z * y.z; c[4 * g + 3] *= 1.0f - y.w * y.w;
         }
         tile_store(a.denc + rc * SV_DP, nt, lh, c, ok);
-        to_frags(c, pn[2 * nt], pn[2 * nt + 1]);
+        to_frags<SPLIT>(c, pn[2 * nt], pn[2 * nt + 1]);
     }
     // ---- dhs^T = W1^T denc^T
 #pragma unroll
@@ -356,7 +416,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
         for (int i = 0; i < 16; ++i) c[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS_D; ++s)
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_ld(wlds, OFF_B3 - OFF_B1 + nt * KS_D + s, lane), pn[s], c, 0, 0, 0);
+            mm<SPLIT>(c, wlds, OFF_B3 - OFF_B1 + nt * KS_D + s, a.frags, OFF_B3 + nt * KS_D + s, lane, pn[s]);
         tile_store(a.dhs + rc * SV_HP, nt, lh, c, ok);
     }
 }
@@ -368,21 +428,48 @@ extern "C" int svae_mlp_frag_elems(void) { return NFRAG * 512; }
 // bf16 weight fragments of the three Linear layers (weights padded as in the flat parameter buffer:
 // w1 [160][224] Encoder.linear1 nb:688, wl [128][160] Model.linear1 nb:729, w2 [160][64] Decoder.linear1 nb:701).
 // frags: svae_mlp_frag_elems() bf16 elements.  Call once per optimizer step (the weights change).
+extern "C" int svae_mlp_prep_prec(const float* w1, const float* wl, const float* w2, void* frags, int prec, void* stream);
 extern "C" int svae_mlp_prep(const float* w1, const float* wl, const float* w2, void* frags, void* stream) {
-    SV_CHECK_ARG(w1 && wl && w2 && frags, "svae_mlp_prep: null pointer");
+    return svae_mlp_prep_prec(w1, wl, w2, frags, 1, stream);
+}
+// prec 2: frags holds 3 * svae_mlp_frag_elems() elements: the hi fragments, then the mid parts (v - hi), then the
+// lo parts (v - hi - mid), each rounded to bf16.
+extern "C" int svae_mlp_prep_prec(const float* w1, const float* wl, const float* w2, void* frags, int prec, void* stream) {
+    SV_CHECK_ARG(w1 && wl && w2 && frags && (prec == 1 || prec == 2), "svae_mlp_prep: bad arguments");
     hipLaunchKernelGGL(mlp_prep_kernel, dim3((NFRAG * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, wl, w2,
-                       (unsigned short*)frags);
+                       (unsigned short*)frags, prec == 2 ? 3 : 1);
     SV_LAUNCH_CHECK();
     return 0;
 }
 
 // Reference interface replaced: Encoder.forward nb:693-696, Model.sample_latent nb:734-750, the KL row term of
 // VAELoss nb:797 and Decoder.linear1 + tanh nb:708-709, for R rows at once.
+extern "C" int svae_mlp_fwd_prec(const float* hs, const float* eps, const void* frags, const float* b1, const float* bl,
+                                 const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R,
+                                 int prec, void* stream);
 extern "C" int svae_mlp_fwd(const float* hs, const float* eps, const void* frags, const float* b1, const float* bl,
                             const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R,
                             void* stream) {
+    return svae_mlp_fwd_prec(hs, eps, frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R, 1, stream);
+}
+// prec 2: the split instantiation (frags from svae_mlp_prep_prec(..., 2)).
+extern "C" int svae_mlp_fwd_prec(const float* hs, const float* eps, const void* frags, const float* b1, const float* bl,
+                                 const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R,
+                                 int prec, void* stream) {
     SV_CHECK_ARG(hs && eps && frags && b1 && bl && b2 && enc && tmp && z && d1 && kl_row, "svae_mlp_fwd: null pointer");
-    SV_CHECK_ARG(R > 0, "svae_mlp_fwd: R = %d", R);
+    SV_CHECK_ARG(R > 0 && (prec == 1 || prec == 2), "svae_mlp_fwd: R = %d, prec = %d", R, prec);
+    if (prec == 2) {
+        MlpFwdArgs a2{hs, eps, (const unsigned short*)frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R, nullptr, nullptr, nullptr, 0, 0, 0};
+        static bool attr2_done = false;
+        if (!attr2_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_FWD * 1024);
+            if (e != hipSuccess) return svae_fail((int)e, "svae_mlp_fwd: LDS attribute: %s", hipGetErrorString(e));
+            attr2_done = true;
+        }
+        hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_FWD * 1024, (hipStream_t)stream, a2);
+        SV_LAUNCH_CHECK();
+        return 0;
+    }
     MlpFwdArgs a{hs, eps, (const unsigned short*)frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R, nullptr, nullptr, nullptr, 0, 0, 0};
     static bool attr_done = false;
     if (!attr_done) {
@@ -422,19 +509,32 @@ extern "C" int svae_mlp_fwd_prep(const float* hs, const float* eps, const void* 
 
 // Reference interface replaced: autograd of the same chain at loss.backward() nb:1205 (data gradients; the
 // weight gradients are svae_gemm calls on dd1/z, dtmp/enc, denc/hs).  dd1 = dL/d(pre-tanh decoder hidden).
+extern "C" int svae_mlp_bwd_prec(const float* dd1, const float* tmp, const float* eps, const float* enc,
+                                 const float* w_kl, const void* frags, float anneal, float* dtmp, float* denc, float* dhs,
+                                 int R, int prec, void* stream);
 extern "C" int svae_mlp_bwd(const float* dd1, const float* tmp, const float* eps, const float* enc,
                             const float* w_kl, const void* frags, float anneal, float* dtmp, float* denc, float* dhs,
                             int R, void* stream) {
+    return svae_mlp_bwd_prec(dd1, tmp, eps, enc, w_kl, frags, anneal, dtmp, denc, dhs, R, 1, stream);
+}
+extern "C" int svae_mlp_bwd_prec(const float* dd1, const float* tmp, const float* eps, const float* enc,
+                                 const float* w_kl, const void* frags, float anneal, float* dtmp, float* denc, float* dhs,
+                                 int R, int prec, void* stream) {
     SV_CHECK_ARG(dd1 && tmp && eps && enc && w_kl && frags && dtmp && denc && dhs, "svae_mlp_bwd: null pointer");
-    SV_CHECK_ARG(R > 0, "svae_mlp_bwd: R = %d", R);
+    SV_CHECK_ARG(R > 0 && (prec == 1 || prec == 2), "svae_mlp_bwd: R = %d, prec = %d", R, prec);
     MlpBwdArgs a{dd1, tmp, eps, enc, w_kl, (const unsigned short*)frags, dtmp, denc, dhs, anneal, R};
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_BWD * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_BWD * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)mlp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_BWD * 1024);
         if (e != hipSuccess) return svae_fail((int)e, "svae_mlp_bwd: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_BWD * 1024, (hipStream_t)stream, a);
+    if (prec == 2)
+        hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_BWD * 1024, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_BWD * 1024, (hipStream_t)stream, a);
     SV_LAUNCH_CHECK();
     return 0;
 }

@@ -95,6 +95,9 @@ struct ProjArgs {
     float* mpart;               // FDH: [NSPLIT][nx] stabiliser of each split
     int nx, ny, ldt;
     const int4* sched;          // per workgroup: (x tile, first y tile, end y tile, slab)
+    // split instantiation only: element distance between the parts of an image (hi at the pointer, mid = RNE(v - hi)
+    // one stride further, lo = RNE(v - hi - mid) two strides further; same layout each): X's, and Y's / Y^T's
+    long long xps, yps;
 };
 
 // two fp32 -> packed bf16 pair (RNE): one v_cvt_pk_bf16_f32
@@ -109,8 +112,23 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// lo part of a packed bf16 pair: RNE(a - hi(a)), RNE(b - hi(b))
+__device__ __forceinline__ unsigned pack_lo(float a, float b, unsigned hw) {
+    return pack_bf16(a - __uint_as_float(hw << 16), b - __uint_as_float(hw & 0xFFFF0000u));
+}
+
 // 8 waves, two per SIMD: the exp / bf16-pack VALU work of one wave issues while the partner's MFMAs execute.
-template <int MODE>
+//
+// SPLIT = the parity instantiation of the same kernel ("prec 2"): every operand is carried as bf16 hi + mid + lo
+// parts (all 24 significant bits) and every product by its six leading terms hi*hi + hi*mid + mid*hi + mid*mid +
+// hi*lo + lo*hi, so the sweep delivers fp32-class logits and gradients through the same constant-column scheme,
+// running stabiliser, split / slab / finish structure.  The additive constants, hi/lo pairs in two columns of the
+// hi images, get their third part in the MID images (against the other operand's hi ones column): bias in column
+// 151 of the items' mid images, the row constant in column 153 of h2b's mid image, the stabiliser in column 155 of
+// the lane's mid X fragment; the pad columns of the lo images are zero.  Staging is the simple form (one tile: its
+// hi, mid and lo images in the three stages' bytes; load, barrier, compute, barrier) since this instantiation is
+// never timed.
+template <int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -125,12 +143,17 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     // resident X fragments: lane (col = li -> x, half lh) element j = X[x][16 s + 8 lh + j]
     const int x = x0 + li;
     const bool xok = x < a.nx;
-    bf16x8 xf[KS1];
+    bf16x8 xf[KS1], xm[SPLIT ? KS1 : 1], xl[SPLIT ? KS1 : 1];
 #pragma unroll
     for (int s = 0; s < KS1; ++s) {
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}, vm = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
         if (xok) v = *reinterpret_cast<const bf16x8*>(a.X + (size_t)x * KP + 16 * s + 8 * lh);
+        if (SPLIT && xok) {
+            vm = *reinterpret_cast<const bf16x8*>(a.X + a.xps + (size_t)x * KP + 16 * s + 8 * lh);
+            vl = *reinterpret_cast<const bf16x8*>(a.X + 2 * a.xps + (size_t)x * KP + 16 * s + 8 * lh);
+        }
         xf[s] = v;
+        if (SPLIT) { xm[s] = vm; xl[s] = vl; }
     }
 
     f32x16 Z[NT2];
@@ -186,6 +209,58 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     for (int q = 0; q < 4; ++q) rb[q] = YIMG_BYTES + li * (BY * 2) + 16 * ((2 * q + lh) ^ sw2);
     float* fs = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES) + wave * 32;
 
+    // Running stabiliser of the softmax (FDH / FWD), shared by both instantiations: see the file header.
+    auto stabilise = [&](f32x16& c1) {
+    if (MODE != MODE_DW) {
+        float tm = fmaxf(c1[0], c1[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) tm = fmaxf(tm, fmaxf(c1[r], c1[r + 1]));
+        // (the two lane halves of a row are only reconciled inside the rare branch)
+        if (__any(tm > thr)) {
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+            const bool need = tm > thr;
+            // raise the stabiliser of the rows that need it; the value used is the one the bf16 hi/lo pair
+            // represents exactly, so the MFMA and the bookkeeping agree
+            const float mn = fmaxf(m_eff + tm, -1.0e4f);
+            const unsigned short hi = sv_f2bf(-mn);
+            const float hif = sv_bf2f(hi);
+            const unsigned short lo = sv_f2bf(-mn - hif);
+            // (split instantiation: a third part, 24 bits in all, in the lane's mid fragment)
+            const unsigned short lo2 = SPLIT ? sv_f2bf((-mn - hif) - sv_bf2f(lo)) : (unsigned short)0;
+            const float mq = need ? -((hif + sv_bf2f(lo)) + sv_bf2f(lo2)) : m_eff;
+            const float delta = m_eff - mq;          // <= 0 (0 for rows left alone)
+            const float f = __builtin_amdgcn_exp2f(delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c1[r] += delta;
+            if (need && lh == 1) {
+                xf[KS1 - 1][C_MH - 152] = (short)hi;
+                xf[KS1 - 1][C_ML - 152] = (short)lo;
+                if (SPLIT) xm[SPLIT ? KS1 - 1 : 0][C_MH - 152] = (short)lo2;
+            }
+            m_eff = mq;
+            if (MODE == MODE_FWD) {
+                l_run *= f;
+            } else {
+                // Z rows are x = (r&3) + 8 (r>>2) + 4 lh: fetch the factors of those rows through LDS
+                if (lh == 0) fs[li] = f;
+                asm volatile("" ::: "memory");      // read by other lanes: keep the compiler from reordering
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 fv = *reinterpret_cast<const float4*>(fs + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int n = 0; n < NT2; ++n) {
+                        Z[n][4 * g + 0] *= fv.x; Z[n][4 * g + 1] *= fv.y;
+                        Z[n][4 * g + 2] *= fv.z; Z[n][4 * g + 3] *= fv.w;
+                    }
+                }
+            }
+            thr = RESCALE_THR;
+        }
+    }
+    };
+
+    if constexpr (!SPLIT) {
     // Three LDS stages; tile t lives in stage (t - t_begin) % 3.  An LDS-DMA piece takes 1-2 us from issue to
     // landed under load (about one tile), so a tile's pieces are issued between one and two tiles ahead:
     // pieces 0,1 of tile t+3 behind the barrier of tile t (into tile t's stage: every wave made its last read of
@@ -282,50 +357,7 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                 asm volatile("" ::: "memory");
                 SV_TS(5)
             }
-            if (MODE != MODE_DW) {
-                float tm = fmaxf(c1[0], c1[1]);
-#pragma unroll
-                for (int r = 2; r < 16; r += 2) tm = fmaxf(tm, fmaxf(c1[r], c1[r + 1]));
-                // (the two lane halves of a row are only reconciled inside the rare branch)
-                if (__any(tm > thr)) {
-                    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-                    const bool need = tm > thr;
-                    // raise the stabiliser of the rows that need it; the value used is the one the bf16 hi/lo pair
-                    // represents exactly, so the MFMA and the bookkeeping agree
-                    const float mn = fmaxf(m_eff + tm, -1.0e4f);
-                    const unsigned short hi = sv_f2bf(-mn);
-                    const float hif = sv_bf2f(hi);
-                    const unsigned short lo = sv_f2bf(-mn - hif);
-                    const float mq = need ? -(hif + sv_bf2f(lo)) : m_eff;
-                    const float delta = m_eff - mq;          // <= 0 (0 for rows left alone)
-                    const float f = __builtin_amdgcn_exp2f(delta);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) c1[r] += delta;
-                    if (need && lh == 1) {
-                        xf[KS1 - 1][C_MH - 152] = (short)hi;
-                        xf[KS1 - 1][C_ML - 152] = (short)lo;
-                    }
-                    m_eff = mq;
-                    if (MODE == MODE_FWD) {
-                        l_run *= f;
-                    } else {
-                        // Z rows are x = (r&3) + 8 (r>>2) + 4 lh: fetch the factors of those rows through LDS
-                        if (lh == 0) fs[li] = f;
-                        asm volatile("" ::: "memory");      // read by other lanes: keep the compiler from reordering
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float4 fv = *reinterpret_cast<const float4*>(fs + 8 * g + 4 * lh);
-#pragma unroll
-                            for (int n = 0; n < NT2; ++n) {
-                                Z[n][4 * g + 0] *= fv.x; Z[n][4 * g + 1] *= fv.y;
-                                Z[n][4 * g + 2] *= fv.z; Z[n][4 * g + 3] *= fv.w;
-                            }
-                        }
-                    }
-                    thr = RESCALE_THR;
-                }
-            }
+            stabilise(c1);
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(c1[r]);
@@ -393,6 +425,80 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
         g_proj_dbg[MODE][wave >> 2][7] = (unsigned long long)(t_end - t_begin);
     }
 #endif
+    } else {
+        // ---- split instantiation: one tile at a time; its hi / mid / lo images in the bytes of stages 0 / 1 / 2
+        const char* sm_ = smem + STAGE_BYTES;
+        const char* sl_ = smem + 2 * STAGE_BYTES;
+        for (int t = t_begin; t < t_end; ++t) {
+            __syncthreads();                      // every wave has made its last read of the tile before
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                const char* yb_ = Yg + (size_t)part * a.yps * 2 + (size_t)t * (BY * KP * 2);
+                const char* tb_ = Tg + (size_t)part * a.yps * 2 + (size_t)t * (BY * 2);
+                char* ly_ = smem + part * STAGE_BYTES + wave * 1024;
+#pragma unroll
+                for (int q_ = 0; q_ < 3 * NIMG; ++q_)
+                    if (q_ < npiece) SV_PIECE(q_, yb_, tb_, ly_)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 c1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c1[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS1; ++s) {          // small terms first
+                    const bf16x8 yh = SV_YA(smem, sub, s), ym = SV_YA(sm_, sub, s), yl = SV_YA(sl_, sub, s);
+                    const int s_ = SPLIT ? s : 0;
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xf[s], c1, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl[s_], c1, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ym, xm[s_], c1, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ym, xf[s], c1, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xm[s_], c1, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xf[s], c1, 0, 0, 0);
+                }
+                stabilise(c1);
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(c1[r]);
+                if (MODE == MODE_FWD) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc += p[r];
+                    l_run += acc;
+                } else {
+                    bf16x8 ph[2], pm[2], pl[2];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        unsigned hw[4], mw[4], lw[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float p0 = p[8 * s2 + 2 * i], p1 = p[8 * s2 + 2 * i + 1];
+                            hw[i] = pack_bf16(p0, p1);
+                            const float r0 = p0 - __uint_as_float(hw[i] << 16), r1 = p1 - __uint_as_float(hw[i] & 0xFFFF0000u);
+                            mw[i] = pack_bf16(r0, r1);
+                            lw[i] = pack_lo(r0, r1, mw[i]);
+                        }
+                        ph[s2] = __builtin_bit_cast(bf16x8, (uint4){hw[0], hw[1], hw[2], hw[3]});
+                        pm[s2] = __builtin_bit_cast(bf16x8, (uint4){mw[0], mw[1], mw[2], mw[3]});
+                        pl[s2] = __builtin_bit_cast(bf16x8, (uint4){lw[0], lw[1], lw[2], lw[3]});
+                    }
+#pragma unroll
+                    for (int i = 0; i < KS1; ++i) {
+                        const bf16x8 th = SV_YB(smem, sub, i), tm = SV_YB(sm_, sub, i), tl = SV_YB(sl_, sub, i);
+                        f32x16& z = Z[i >> 1];
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[i & 1], th, z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i & 1], tl, z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i & 1], tm, z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[i & 1], th, z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i & 1], tm, z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[i & 1], th, z, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
 #undef SV_YA
 #undef SV_YB
 #undef SV_PAIR
@@ -431,8 +537,14 @@ __device__ __forceinline__ int korder(int y) { return (y & ~12) | ((y & 4) << 1)
 template <int ROWS>
 __global__ void proj_prep_kernel(const float* __restrict__ src, const float* __restrict__ bias,
                                  unsigned short* __restrict__ dst, unsigned short* __restrict__ dsts,
-                                 unsigned short* __restrict__ dstT, int n, int n_pad, int ldt, int row0) {
+                                 unsigned short* __restrict__ dstT, int n, int n_pad, int ldt, int row0,
+                                 long long ps) {
+    // ps > 0 (split instantiation): also the mid and lo parts of the three copies, ps and 2 ps elements behind each
+    // -- RNE(v - hi), RNE(v - hi - mid) in the data columns; zero in the constant columns except the THIRD part of
+    // the bias (column 151 of the items' mid images)
     __shared__ unsigned short tile[32][KP + 2];
+    __shared__ unsigned short tile_m[32][KP + 2];
+    __shared__ unsigned short tile_l[32][KP + 2];
     const int r0 = row0 + blockIdx.x * 32;
     const unsigned short one = 0x3F80;
     for (int i = threadIdx.x; i < 32 * KP; i += blockDim.x) {
@@ -440,11 +552,18 @@ __global__ void proj_prep_kernel(const float* __restrict__ src, const float* __r
         const int row = r0 + r;
         const bool live = row < n;
         unsigned short hp = 0, hs = 0;          // plain copy, scaled copy
+        unsigned short mp = 0, ms = 0;          // their mid parts
+        unsigned short lp = 0, ls = 0;          // their lo parts
         if (c < SV_D) {
             if (live) {
                 const float v = src[(size_t)row * KP + c];
                 hp = sv_f2bf(v);
                 hs = sv_f2bf(v * LOG2E);
+                const float rp = v - sv_bf2f(hp), rs = v * LOG2E - sv_bf2f(hs);
+                mp = sv_f2bf(rp);
+                ms = sv_f2bf(rs);
+                lp = sv_f2bf(rp - sv_bf2f(mp));
+                ls = sv_f2bf(rs - sv_bf2f(ms));
             }
         } else if (ROWS) {
             if (c == C_ONE) hp = live ? one : 0;
@@ -455,7 +574,9 @@ __global__ void proj_prep_kernel(const float* __restrict__ src, const float* __r
                 if (live) {
                     const float b = bias[row] * LOG2E;
                     const unsigned short hi = sv_f2bf(b);
-                    hp = hs = (c == C_BH) ? hi : sv_f2bf(b - sv_bf2f(hi));
+                    const unsigned short lo = sv_f2bf(b - sv_bf2f(hi));
+                    hp = hs = (c == C_BH) ? hi : lo;
+                    if (c == C_BH) mp = ms = sv_f2bf((b - sv_bf2f(hi)) - sv_bf2f(lo));
                 } else if (c == C_BH) {
                     hp = sv_f2bf(NEG_BIG);
                 }
@@ -464,15 +585,29 @@ __global__ void proj_prep_kernel(const float* __restrict__ src, const float* __r
             if (c == C_MH || c == C_ML) hp = one;
         }
         tile[r][c] = hp;
+        tile_m[r][c] = mp;
+        tile_l[r][c] = lp;
         if (row < n_pad) {
             dst[(size_t)row * KP + c] = hp;
             dsts[(size_t)row * KP + c] = hs;
+            if (ps > 0) {
+                dst[ps + (size_t)row * KP + c] = mp;
+                dsts[ps + (size_t)row * KP + c] = ms;
+                dst[2 * ps + (size_t)row * KP + c] = lp;
+                dsts[2 * ps + (size_t)row * KP + c] = ls;
+            }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * KP; i += blockDim.x) {
         const int c = i / 32, r = i % 32;
-        if (r0 + r < ldt) dstT[(size_t)c * ldt + korder(r0 + r)] = tile[r][c];
+        if (r0 + r < ldt) {
+            dstT[(size_t)c * ldt + korder(r0 + r)] = tile[r][c];
+            if (ps > 0) {
+                dstT[ps + (size_t)c * ldt + korder(r0 + r)] = tile_m[r][c];
+                dstT[2 * ps + (size_t)c * ldt + korder(r0 + r)] = tile_l[r][c];
+            }
+        }
     }
 }
 
@@ -519,7 +654,8 @@ __global__ void proj_fdh_finish_kernel(const float* __restrict__ slabs, const fl
                                        const float* __restrict__ b3, const int* __restrict__ tgt,
                                        const float* __restrict__ w_nll, int R, int K, float* __restrict__ dd1,
                                        float* __restrict__ nll_row, float* __restrict__ lse_out,
-                                       unsigned short* __restrict__ h2b, int ns_q, int ns_rem) {
+                                       unsigned short* __restrict__ h2b, int ns_q, int ns_rem,
+                                       unsigned short* __restrict__ h2b_lo) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -582,8 +718,11 @@ __global__ void proj_fdh_finish_kernel(const float* __restrict__ slabs, const fl
         lse_out[row] = lse;
         const float rc = nr > 0 ? log2f(c) - lse2 : NEG_BIG;
         const unsigned short hi = sv_f2bf(rc);
+        const unsigned short lo = sv_f2bf(rc - sv_bf2f(hi));
         h2b[(size_t)row * KP + C_RH] = hi;
-        h2b[(size_t)row * KP + C_RL] = sv_f2bf(rc - sv_bf2f(hi));
+        h2b[(size_t)row * KP + C_RL] = lo;
+        // split instantiation: the third part rides in the MID image (against the ones column of w3s's hi image)
+        if (h2b_lo) h2b_lo[(size_t)row * KP + C_RH] = nr > 0 ? sv_f2bf((rc - sv_bf2f(hi)) - sv_bf2f(lo)) : (unsigned short)0;
     }
 }
 
@@ -715,19 +854,19 @@ __global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __rest
 // 600 us in the first GPU process of a freshly booted box -- which made a bracketed step host-bound.)
 thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
 
-template <int MODE>
+template <int MODE, bool SPLIT = false>
 int launch_proj(ProjArgs a, int nwg, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)proj_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)proj_kernel<MODE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return svae_fail((int)e, "svae_proj: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     if (g_time_start != nullptr && g_time_stop != nullptr) {
-        hipExtLaunchKernelGGL((proj_kernel<MODE>), dim3(nwg), dim3(512), LDS_BYTES, st, g_time_start, g_time_stop, 0, a);
+        hipExtLaunchKernelGGL((proj_kernel<MODE, SPLIT>), dim3(nwg), dim3(512), LDS_BYTES, st, g_time_start, g_time_stop, 0, a);
         g_time_start = g_time_stop = nullptr;
     } else {
-        hipLaunchKernelGGL((proj_kernel<MODE>), dim3(nwg), dim3(512), LDS_BYTES, st, a);
+        hipLaunchKernelGGL((proj_kernel<MODE, SPLIT>), dim3(nwg), dim3(512), LDS_BYTES, st, a);
     }
     SV_LAUNCH_CHECK();
     return 0;
@@ -849,27 +988,43 @@ extern "C" int svae_proj_prep_rows(const float* h2, int R, int R_pad, void* h2b,
 }
 
 // The same for rows [row0, row1) only (multiples of 32; all pointers are those of the whole arrays).
+extern "C" int svae_proj_prep_rows_range_split(const float* h2, int R, int R_pad, int row0, int row1, void* h2b, void* h2s,
+                                               void* h2tb, long long part_stride, void* stream);
 extern "C" int svae_proj_prep_rows_range(const float* h2, int R, int R_pad, int row0, int row1, void* h2b, void* h2s,
                                          void* h2tb, void* stream) {
+    return svae_proj_prep_rows_range_split(h2, R, R_pad, row0, row1, h2b, h2s, h2tb, 0, stream);
+}
+// part_stride > 0: also the mid and lo parts of the three copies for the split instantiation, part_stride and
+// 2 part_stride ELEMENTS behind each copy (part_stride >= R_pad * 160; 0: bf16 copies only).
+extern "C" int svae_proj_prep_rows_range_split(const float* h2, int R, int R_pad, int row0, int row1, void* h2b, void* h2s,
+                                               void* h2tb, long long part_stride, void* stream) {
     SV_CHECK_ARG(h2 && h2b && h2s && h2tb && R > 0 && R_pad >= R && (R_pad % BY) == 0, "svae_proj_prep_rows: bad arguments");
+    SV_CHECK_ARG(part_stride == 0 || (part_stride >= (long long)R_pad * KP && (part_stride % 8) == 0),
+                 "svae_proj_prep_rows: bad part stride %lld", part_stride);
     SV_CHECK_ARG(row0 >= 0 && row0 < row1 && row1 <= R_pad && (row0 % 32) == 0 && (row1 % 32) == 0,
                  "svae_proj_prep_rows_range: bad range [%d, %d) of %d", row0, row1, R_pad);
     hipLaunchKernelGGL(proj_prep_kernel<1>, dim3((row1 - row0) / 32), dim3(256), 0, (hipStream_t)stream, h2,
                        (const float*)nullptr, (unsigned short*)h2b, (unsigned short*)h2s, (unsigned short*)h2tb, R, R_pad,
-                       R_pad, row0);
+                       R_pad, row0, part_stride);
     SV_LAUNCH_CHECK();
     return 0;
 }
 
 // bf16 operand copies of Decoder.linear2 (nb:704): w3 [I][160] fp32, b3 [I]  ->  w3b, w3s [I_pad][160],
-// w3tb [160][I_pad]; I_pad % 64 == 0.
-extern "C" int svae_proj_prep_items(const float* w3, const float* b3, int I, int I_pad, void* w3b, void* w3s,
-                                    void* w3tb, void* stream) {
+// w3tb [160][I_pad]; I_pad % 64 == 0.  _split: part_stride as above (>= I_pad * 160).
+extern "C" int svae_proj_prep_items_split(const float* w3, const float* b3, int I, int I_pad, void* w3b, void* w3s,
+                                          void* w3tb, long long part_stride, void* stream) {
     SV_CHECK_ARG(w3 && b3 && w3b && w3s && w3tb && I > 0 && I_pad >= I && (I_pad % BY) == 0, "svae_proj_prep_items: bad arguments");
+    SV_CHECK_ARG(part_stride == 0 || (part_stride >= (long long)I_pad * KP && (part_stride % 8) == 0),
+                 "svae_proj_prep_items: bad part stride %lld", part_stride);
     hipLaunchKernelGGL(proj_prep_kernel<0>, dim3(I_pad / 32), dim3(256), 0, (hipStream_t)stream, w3, b3,
-                       (unsigned short*)w3b, (unsigned short*)w3s, (unsigned short*)w3tb, I, I_pad, I_pad, 0);
+                       (unsigned short*)w3b, (unsigned short*)w3s, (unsigned short*)w3tb, I, I_pad, I_pad, 0, part_stride);
     SV_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int svae_proj_prep_items(const float* w3, const float* b3, int I, int I_pad, void* w3b, void* w3s,
+                                    void* w3tb, void* stream) {
+    return svae_proj_prep_items_split(w3, b3, I, I_pad, w3b, w3s, w3tb, 0, stream);
 }
 
 // a schedule (svae_proj_schedule) must cover every x tile of nx rows exactly ns_j times: cheap consistency check
@@ -882,14 +1037,31 @@ static bool sched_ok(int nx, int nwg, int ns_q, int ns_rem) {
 
 // Reference interface replaced: Decoder.linear2 + F.log_softmax + likelihood of VAELoss.forward
 // (nb:710, nb:802-808), loss only (scoring).  part = float2 [8][R] scratch.  Outputs nll_row[R], lse[R].
+extern "C" int svae_proj_nll_fwd_split(const void* h2s, const void* w3b, const float* h2, const float* w3,
+                                       const float* b3, const int* tgt, int R, int I, int K, float* part, float* nll_row,
+                                       float* lse, const int* sched, int nwg, int ns_q, int ns_rem,
+                                       long long row_part_stride, long long item_part_stride, void* stream);
 extern "C" int svae_proj_nll_fwd(const void* h2s, const void* w3b, const float* h2, const float* w3, const float* b3,
                                  const int* tgt, int R, int I, int K, float* part, float* nll_row, float* lse,
                                  const int* sched, int nwg, int ns_q, int ns_rem, void* stream) {
+    return svae_proj_nll_fwd_split(h2s, w3b, h2, w3, b3, tgt, R, I, K, part, nll_row, lse, sched, nwg, ns_q, ns_rem,
+                                   0, 0, stream);
+}
+// row_part_stride / item_part_stride (both > 0 or both 0): the part strides the row and item copies were prepared
+// with (svae_proj_prep_*_split) -> the split instantiation (fp32-class logits); 0: bf16.
+extern "C" int svae_proj_nll_fwd_split(const void* h2s, const void* w3b, const float* h2, const float* w3,
+                                       const float* b3, const int* tgt, int R, int I, int K, float* part, float* nll_row,
+                                       float* lse, const int* sched, int nwg, int ns_q, int ns_rem,
+                                       long long row_part_stride, long long item_part_stride, void* stream) {
     SV_CHECK_ARG(h2s && w3b && h2 && w3 && b3 && tgt && part && nll_row && lse && sched, "svae_proj_nll_fwd: null pointer");
     SV_CHECK_ARG(R > 0 && I > 0 && K >= 1, "svae_proj_nll_fwd: bad shape");
+    SV_CHECK_ARG((row_part_stride > 0) == (item_part_stride > 0) && row_part_stride >= 0,
+                 "svae_proj_nll_fwd: pass both part strides or none");
     SV_CHECK_ARG(sched_ok(R, nwg, ns_q, ns_rem), "svae_proj_nll_fwd: schedule does not belong to R = %d", R);
-    ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, nullptr, part, nullptr, R, I, 0, (const int4*)sched};
-    if (int e = launch_proj<MODE_FWD>(a, nwg, (hipStream_t)stream)) return e;
+    ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, nullptr, part, nullptr, R, I, 0, (const int4*)sched,
+               row_part_stride, item_part_stride};
+    if (int e = row_part_stride > 0 ? launch_proj<MODE_FWD, true>(a, nwg, (hipStream_t)stream)
+                                    : launch_proj<MODE_FWD>(a, nwg, (hipStream_t)stream)) return e;
     hipLaunchKernelGGL(proj_fwd_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (const float2*)part, h2, w3, b3, tgt, R, K, nll_row, lse, ns_q, ns_rem);
     SV_LAUNCH_CHECK();
@@ -899,52 +1071,69 @@ extern "C" int svae_proj_nll_fwd(const void* h2s, const void* w3b, const float* 
 // Reference interface replaced: the same forward AND the hidden-side half of its autograd (nb:1205) in one
 // sweep over the items.  Outputs nll_row[R], lse[R], dd1 [R][160] = dL/d(pre-tanh decoder hidden) (tanh of
 // Decoder.linear1, nb:709), and the row constants in columns 153/154 of h2b that svae_proj_nll_bwd_dw needs.
-// slabs: scratch of 8 * R * 160 floats; mpart: 8 * R floats.  parts: 1 = sweep kernel, 2 = finish (3 = both).
+// slabs: scratch of 16 * R * 160 floats; mpart: 16 * R floats.  parts: 1 = sweep kernel, 2 = finish (3 = both).
+// _split: the part strides of the row copies (h2s, h2b) and of the item copies (w3b, w3tb); both 0 = bf16.
+extern "C" int svae_proj_nll_fwd_dh_split(const void* h2s, void* h2b, const void* w3b, const void* w3tb, int I_pad,
+                                          const float* h2, const float* w3, const float* b3, const int* tgt,
+                                          const float* w_nll, int R, int I, int K, float* slabs, float* mpart,
+                                          float* nll_row, float* lse, float* dd1, const int* sched, int nwg, int ns_q,
+                                          int ns_rem, int parts, long long row_part_stride, long long item_part_stride,
+                                          void* stream) {
+    SV_CHECK_ARG(h2s && h2b && w3b && w3tb && h2 && w3 && b3 && tgt && w_nll && slabs && mpart && nll_row && lse && dd1,
+                 "svae_proj_nll_fwd_dh: null pointer");
+    SV_CHECK_ARG(R > 0 && I > 0 && K >= 1 && I_pad >= I && (I_pad % BY) == 0 && parts > 0 && parts < 4,
+                 "svae_proj_nll_fwd_dh: bad shape");
+    const bool split = row_part_stride > 0;
+    SV_CHECK_ARG(split == (item_part_stride > 0) && row_part_stride >= 0, "svae_proj_nll_fwd_dh: pass both part strides or none");
+    SV_CHECK_ARG(sched && sched_ok(R, nwg, ns_q, ns_rem), "svae_proj_nll_fwd_dh: schedule does not belong to R = %d", R);
+    hipStream_t st = (hipStream_t)stream;
+    if (parts & 1) {
+        ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, (const unsigned short*)w3tb, slabs, mpart,
+                   R, I, I_pad, (const int4*)sched, row_part_stride, item_part_stride};
+        if (int e = split ? launch_proj<MODE_FDH, true>(a, nwg, st) : launch_proj<MODE_FDH>(a, nwg, st)) return e;
+    }
+    if (parts & 2) {
+        hipLaunchKernelGGL(proj_fdh_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, st, slabs, mpart, h2, w3, b3, tgt,
+                           w_nll, R, K, dd1, nll_row, lse, (unsigned short*)h2b, ns_q, ns_rem,
+                           split ? (unsigned short*)h2b + row_part_stride : (unsigned short*)nullptr);
+        SV_LAUNCH_CHECK();
+    }
+    return 0;
+}
 extern "C" int svae_proj_nll_fwd_dh(const void* h2s, void* h2b, const void* w3b, const void* w3tb, int I_pad,
                                     const float* h2, const float* w3, const float* b3, const int* tgt,
                                     const float* w_nll, int R, int I, int K, float* slabs, float* mpart,
                                     float* nll_row, float* lse, float* dd1, const int* sched, int nwg, int ns_q,
                                     int ns_rem, int parts, void* stream) {
-    SV_CHECK_ARG(h2s && h2b && w3b && w3tb && h2 && w3 && b3 && tgt && w_nll && slabs && mpart && nll_row && lse && dd1,
-                 "svae_proj_nll_fwd_dh: null pointer");
-    SV_CHECK_ARG(R > 0 && I > 0 && K >= 1 && I_pad >= I && (I_pad % BY) == 0 && parts > 0 && parts < 4,
-                 "svae_proj_nll_fwd_dh: bad shape");
-    SV_CHECK_ARG(sched && sched_ok(R, nwg, ns_q, ns_rem), "svae_proj_nll_fwd_dh: schedule does not belong to R = %d", R);
-    hipStream_t st = (hipStream_t)stream;
-    if (parts & 1) {
-        ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, (const unsigned short*)w3tb, slabs, mpart,
-                   R, I, I_pad, (const int4*)sched};
-        if (int e = launch_proj<MODE_FDH>(a, nwg, st)) return e;
-    }
-    if (parts & 2) {
-        hipLaunchKernelGGL(proj_fdh_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, st, slabs, mpart, h2, w3, b3, tgt,
-                           w_nll, R, K, dd1, nll_row, lse, (unsigned short*)h2b, ns_q, ns_rem);
-        SV_LAUNCH_CHECK();
-    }
-    return 0;
+    return svae_proj_nll_fwd_dh_split(h2s, h2b, w3b, w3tb, I_pad, h2, w3, b3, tgt, w_nll, R, I, K, slabs, mpart, nll_row,
+                                      lse, dd1, sched, nwg, ns_q, ns_rem, parts, 0, 0, stream);
 }
 
 // Reference interface replaced: the weight-side half of the autograd of the same (nb:1205): gw3 [I_pad][160],
 // gb3 [I_pad].  Needs svae_proj_nll_fwd_dh of the same batch before it (row constants in h2b).
-// slabs: scratch of 8 * I * 160 floats.  occ_off [I+1] / occ_row: target occurrences by item; occ_items [I]: the
+// slabs: scratch of 16 * I * 160 floats.  occ_off [I+1] / occ_row: target occurrences by item; occ_items [I]: the
 // items ordered by occurrence count (descending), the first nocc_long of them having more than svae_proj_occ_long().
 // I_rows >= I: rows of gw3 / gb3 (rows >= I are written as zero).  parts: 1 = sweep kernel, 2 = finish (3 = both).
-extern "C" int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad,
-                                    int I, int I_rows, const float* h2, const float* w_nll, const int* occ_off,
-                                    const int* occ_row, const int* occ_items, int nocc_long, float* slabs, float* gw3,
-                                    float* gb3, const int* sched, int nwg, int ns_q, int ns_rem, int parts,
-                                    void* stream) {
+// _split: the part strides of the item copy (w3s) and of the row copies (h2b, h2tb); both 0 = bf16.
+extern "C" int svae_proj_nll_bwd_dw_split(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad,
+                                          int I, int I_rows, const float* h2, const float* w_nll, const int* occ_off,
+                                          const int* occ_row, const int* occ_items, int nocc_long, float* slabs,
+                                          float* gw3, float* gb3, const int* sched, int nwg, int ns_q, int ns_rem,
+                                          int parts, long long row_part_stride, long long item_part_stride,
+                                          void* stream) {
     SV_CHECK_ARG(w3s && h2b && h2tb && h2 && w_nll && occ_off && occ_row && occ_items && slabs && gw3 && gb3,
                  "svae_proj_nll_bwd_dw: null pointer");
     SV_CHECK_ARG(nocc_long >= 0 && nocc_long <= I, "svae_proj_nll_bwd_dw: bad nocc_long");
     SV_CHECK_ARG(R > 0 && I > 0 && I_rows >= I && R_pad >= R && (R_pad % BY) == 0 && parts > 0 && parts < 4,
                  "svae_proj_nll_bwd_dw: bad shape");
+    const bool split = row_part_stride > 0;
+    SV_CHECK_ARG(split == (item_part_stride > 0) && row_part_stride >= 0, "svae_proj_nll_bwd_dw: pass both part strides or none");
     SV_CHECK_ARG(sched && sched_ok(I, nwg, ns_q, ns_rem), "svae_proj_nll_bwd_dw: schedule does not belong to I = %d", I);
     hipStream_t st = (hipStream_t)stream;
     if (parts & 1) {
         ProjArgs a{(const unsigned short*)w3s, (const unsigned short*)h2b, (const unsigned short*)h2tb, slabs, nullptr,
-                   I, R, R_pad, (const int4*)sched};
-        if (int e = launch_proj<MODE_DW>(a, nwg, st)) return e;
+                   I, R, R_pad, (const int4*)sched, item_part_stride, row_part_stride};
+        if (int e = split ? launch_proj<MODE_DW, true>(a, nwg, st) : launch_proj<MODE_DW>(a, nwg, st)) return e;
     }
     if (parts & 2) {
         if (nocc_long > 0)
@@ -955,4 +1144,12 @@ extern "C" int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void
         SV_LAUNCH_CHECK();
     }
     return 0;
+}
+extern "C" int svae_proj_nll_bwd_dw(const void* w3s, const void* h2b, const void* h2tb, int R, int R_pad,
+                                    int I, int I_rows, const float* h2, const float* w_nll, const int* occ_off,
+                                    const int* occ_row, const int* occ_items, int nocc_long, float* slabs, float* gw3,
+                                    float* gb3, const int* sched, int nwg, int ns_q, int ns_rem, int parts,
+                                    void* stream) {
+    return svae_proj_nll_bwd_dw_split(w3s, h2b, h2tb, R, R_pad, I, I_rows, h2, w_nll, occ_off, occ_row, occ_items,
+                                      nocc_long, slabs, gw3, gb3, sched, nwg, ns_q, ns_rem, parts, 0, 0, stream);
 }

@@ -33,7 +33,8 @@ struct RgArgs {
     float* y;                     // [R][N]
     int R, nrb;                   // rows, row blocks of 128
     int ldx;                      // row stride of x (floats, >= K)
-    const unsigned short* frags_lo;   // SPLIT: the lo parts of the weight, same fragment order (read from L2, not staged)
+    const unsigned short* frags_lo;   // SPLIT: the mid parts of the weight, same fragment order, followed (K*N elements
+                                      // further) by the lo parts; read from L2, not staged
 };
 
 __device__ __forceinline__ unsigned rg_pk2(float a, float b) {
@@ -63,9 +64,9 @@ __device__ __forceinline__ void rg_glds16(const char* g, char* l) {
 // Grid: id -> (row block, chunk) with the chunks of a row block 8 ids apart, i.e. on the same XCD (id % 8) and
 // dispatched together: the row block is then read from HBM once and from that XCD's L2 by the other chunks.
 // XB: x holds bf16 elements (ldx in elements): a k-step of a lane is one 16-byte load and needs no conversion.
-// SPLIT (fp32 rows only): the parity instantiation.  Same tiling and fragment order; a product is carried as
-// hi*hi + hi*lo + lo*hi of bf16 hi / lo parts (rows split in registers, the weight's lo fragments read straight from
-// L2: the LDS is full of the hi fragments).
+// SPLIT (fp32 rows only): the parity instantiation.  Same tiling and fragment order; operands as bf16 hi + mid + lo
+// parts (24 bits), a product as the six leading terms (rows split in registers, the weight's mid / lo fragments read
+// straight from L2: the LDS is full of the hi fragments).
 template <int WHICH, bool XB, bool SPLIT = false>
 __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
     static_assert(!(XB && SPLIT), "the split instantiation reads fp32 rows");
@@ -127,22 +128,24 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
             if (g + PDX < NG) RG_LOADX(g + PDX)
 #pragma unroll
             for (int s = 0; s < XG; ++s) {
-                bf16x8 xf, xl;
+                bf16x8 xf, xm, xl;
                 if (XB) {
                     xf = __builtin_bit_cast(bf16x8, xraw[g % (PDX + 1)][s][0]);
                 } else if (SPLIT) {
                     const float4 lo = xraw[g % (PDX + 1)][s][0], hi = xraw[g % (PDX + 1)][s][XB ? 0 : 1];
                     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    uint4 u, w;
-                    u.x = rg_pk2(v[0], v[1]); u.y = rg_pk2(v[2], v[3]); u.z = rg_pk2(v[4], v[5]); u.w = rg_pk2(v[6], v[7]);
-                    const unsigned hw[4] = {u.x, u.y, u.z, u.w};
-                    unsigned lw[4];
+                    unsigned hw[4], mw[4], lw[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        lw[i] = rg_pk2(v[2 * i] - __uint_as_float(hw[i] << 16), v[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u));
-                    w.x = lw[0]; w.y = lw[1]; w.z = lw[2]; w.w = lw[3];
-                    xf = __builtin_bit_cast(bf16x8, u);
-                    xl = __builtin_bit_cast(bf16x8, w);
+                    for (int i = 0; i < 4; ++i) {
+                        hw[i] = rg_pk2(v[2 * i], v[2 * i + 1]);
+                        const float r0 = v[2 * i] - __uint_as_float(hw[i] << 16);
+                        const float r1 = v[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u);
+                        mw[i] = rg_pk2(r0, r1);
+                        lw[i] = rg_pk2(r0 - __uint_as_float(mw[i] << 16), r1 - __uint_as_float(mw[i] & 0xFFFF0000u));
+                    }
+                    xf = __builtin_bit_cast(bf16x8, (uint4){hw[0], hw[1], hw[2], hw[3]});
+                    xm = __builtin_bit_cast(bf16x8, (uint4){mw[0], mw[1], mw[2], mw[3]});
+                    xl = __builtin_bit_cast(bf16x8, (uint4){lw[0], lw[1], lw[2], lw[3]});
                 } else {
                     const float4 lo = xraw[g % (PDX + 1)][s][0], hi = xraw[g % (PDX + 1)][s][1];
                     uint4 u;
@@ -154,10 +157,14 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
                 for (int t = 0; t < NTC; ++t) {
                     const bf16x8 wf = __builtin_bit_cast(bf16x8, st[(ks * NTC + t) * 64]);
                     if (SPLIT) {
-                        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(
-                            a.frags_lo + ((size_t)c * CT * KS + (size_t)ks * NTC + t) * 512 + lane * 8);
+                        const unsigned short* fp_ = a.frags_lo + ((size_t)c * CT * KS + (size_t)ks * NTC + t) * 512 + lane * 8;
+                        const bf16x8 wm = *reinterpret_cast<const bf16x8*>(fp_);
+                        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(fp_ + (size_t)K * N);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xf, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xf, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xm, acc[t], 0, 0, 0);
                     }
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t], 0, 0, 0);
                 }
@@ -203,7 +210,12 @@ __global__ void rowgemm_prep_kernel(const float* __restrict__ src, int sn, int s
         const float v = src[(size_t)n * sn + (size_t)(k0 + j) * sk];
         const unsigned short h = sv_f2bf(v);
         d[j] = h;
-        if (dst_lo) (dst_lo + (d - dst))[j] = sv_f2bf(v - sv_bf2f(h));
+        if (dst_lo) {      // mid part, then (K*N elements further) the lo part
+            const float r = v - sv_bf2f(h);
+            const unsigned short m = sv_f2bf(r);
+            (dst_lo + (d - dst))[j] = m;
+            (dst_lo + (size_t)S::K * S::N + (d - dst))[j] = sv_f2bf(r - sv_bf2f(m));
+        }
     }
     (void)NT;
 }
@@ -233,8 +245,8 @@ extern "C" int svae_rowgemm_frag_elems(int which) {
 }
 
 // wih: gru.weight_ih_l0 as stored, [672][256] fp32 (gate rows padded 200 -> 224 with zeros).
-// prec 1: bf16 fragments (svae_rowgemm_frag_elems elements); prec 2: hi fragments followed by the lo fragments
-// (v - hi, rounded to bf16) for the split instantiation: 2 * svae_rowgemm_frag_elems elements.
+// prec 1: bf16 fragments (svae_rowgemm_frag_elems elements); prec 2: hi fragments followed by the mid and the lo
+// fragments (v - hi and v - hi - mid, rounded to bf16) for the split instantiation: 3 * svae_rowgemm_frag_elems.
 extern "C" int svae_rowgemm_prep_prec(const float* wih, int which, void* frags, int prec, void* stream) {
     SV_CHECK_ARG(wih && frags && (which == 0 || which == 1) && (prec == 1 || prec == 2), "svae_rowgemm_prep: bad arguments");
     unsigned short* lo = prec == 2 ? (unsigned short*)frags + SV_G * SV_E : nullptr;

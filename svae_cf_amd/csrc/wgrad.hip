@@ -36,23 +36,25 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
 
 // ABF: dY holds bf16 elements (the GRU's merged gradient array): its tile is 16 rows x 128 columns x 2 B = 4 KiB, one
 // LDS-DMA piece (4 rows) per wave, and a fragment is built from 2-byte reads without conversion.
-// hi / lo parts of 8 fp32 values as two bf16 fragments: hi = RNE(v), lo = RNE(v - hi); hi + lo carries 16 significant
-// bits of v.  The split instantiation (SPLIT) contracts hi*hi + hi*lo + lo*hi: fp32-class products on the bf16 pipe.
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-    uint4 h, l;
-    h.x = pk2(v[0], v[1]); h.y = pk2(v[2], v[3]); h.z = pk2(v[4], v[5]); h.w = pk2(v[6], v[7]);
-    const unsigned hw[4] = {h.x, h.y, h.z, h.w};
-    unsigned lw[4];
+// hi / mid / lo parts of 8 fp32 values as three bf16 fragments: hi = RNE(v), mid = RNE(v - hi), lo = RNE(v - hi - mid);
+// together they carry all 24 significant bits of v.  The split instantiation (SPLIT) contracts
+// hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi: fp32-class products on the bf16 pipe.
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    unsigned hw[4], mw[4], lw[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        lw[i] = pk2(v[2 * i] - __uint_as_float(hw[i] << 16), v[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u));
-    l.x = lw[0]; l.y = lw[1]; l.z = lw[2]; l.w = lw[3];
-    hi = __builtin_bit_cast(bf16x8, h);
-    lo = __builtin_bit_cast(bf16x8, l);
+    for (int i = 0; i < 4; ++i) {
+        hw[i] = pk2(v[2 * i], v[2 * i + 1]);
+        const float r0 = v[2 * i] - __uint_as_float(hw[i] << 16), r1 = v[2 * i + 1] - __uint_as_float(hw[i] & 0xFFFF0000u);
+        mw[i] = pk2(r0, r1);
+        lw[i] = pk2(r0 - __uint_as_float(mw[i] << 16), r1 - __uint_as_float(mw[i] & 0xFFFF0000u));
+    }
+    hi = __builtin_bit_cast(bf16x8, (uint4){hw[0], hw[1], hw[2], hw[3]});
+    mid = __builtin_bit_cast(bf16x8, (uint4){mw[0], mw[1], mw[2], mw[3]});
+    lo = __builtin_bit_cast(bf16x8, (uint4){lw[0], lw[1], lw[2], lw[3]});
 }
 
-// SPLIT (fp32 dY only): the parity instantiation -- same staging, tiling and slab order, every product carried as
-// hi*hi + hi*lo + lo*hi of bf16 hi/lo operand parts.
+// SPLIT (fp32 dY only): the parity instantiation -- same staging, tiling and slab order, every product carried by
+// the six leading terms of (hi + mid + lo) x (hi + mid + lo).
 template <bool ABF, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     static_assert(!(ABF && SPLIT), "the split instantiation reads fp32 operands");
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             for (int k = 0; k < WK; ++k) cs += ABF ? sv_bf2f(sAh[k * WM + tid]) : sA[k * WM + tid];
         }
         // fragment of a 32-column group: lane (li, lh) takes rows 8 lh .. 8 lh + 7 of column base + li
-        bf16x8 fa[2], fb[2], fal[2], fbl[2];
+        bf16x8 fa[2], fb[2], fam[2], fbm[2], fal[2], fbl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             uint4 u;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             } else if (SPLIT) {
                 const float* p = sA + (8 * lh) * WM + wm + 32 * i + li;
                 const float v[8] = {p[0], p[WM], p[2 * WM], p[3 * WM], p[4 * WM], p[5 * WM], p[6 * WM], p[7 * WM]};
-                split8(v, fa[i], fal[i]);
+                split8(v, fa[i], fam[i], fal[i]);
             } else {
                 const float* p = sA + (8 * lh) * WM + wm + 32 * i + li;
                 u.x = pk2(p[0], p[WM]); u.y = pk2(p[2 * WM], p[3 * WM]);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             const float* p = sB + (8 * lh) * WN + wn + 32 * j + li;
             if (SPLIT) {
                 const float v[8] = {p[0], p[WN], p[2 * WN], p[3 * WN], p[4 * WN], p[5 * WN], p[6 * WN], p[7 * WN]};
-                split8(v, fb[j], fbl[j]);
+                split8(v, fb[j], fbm[j], fbl[j]);
             } else {
                 uint4 u;
                 u.x = pk2(p[0], p[WN]); u.y = pk2(p[2 * WN], p[3 * WN]);
@@ -175,6 +177,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                 if (SPLIT) {       // small terms first
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fbl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fam[i], fbm[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fam[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fbm[j], acc[i][j], 0, 0, 0);
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }

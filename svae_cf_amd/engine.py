@@ -18,6 +18,12 @@ from .layout import D, DP, E, G, HP, L, ParamLayout
 
 PREC_FP32 = 0
 PREC_BF16 = 1
+# The fused bf16 kernels in their SPLIT instantiation: operands as bf16 hi + mid + lo parts (all 24 significant bits),
+# products by their six leading terms (fp32-class results from the same kernel templates, work division, slab /
+# finish structure as PREC_BF16: the projection sweeps, the MLP chain, the row-panel and weight-gradient GEMMs).  The
+# parity gates run through it; it does six times the MFMA work of PREC_BF16 and is never timed.  The GRU recurrence
+# runs its exact fp32 kernels.
+PREC_SPLIT = 2
 
 
 # Launch stream of the kernels.  torch.cuda.current_stream() costs ~8 us of host time (device-index and
@@ -67,7 +73,9 @@ class SVAEEngine:
         self.layout = ParamLayout(total_items)
         self.I, self.IP = self.layout.I, self.layout.IP
         self.prec = prec
-        self.gru_prec = prec
+        self.split = prec == PREC_SPLIT
+        self.gru_prec = PREC_FP32 if self.split else prec
+        self.gemm_prec = PREC_FP32 if self.split else prec         # generic GEMM (dense surface): fp32 or bf16
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
         n = self.layout.total
         f32 = dict(device=self.device, dtype=torch.float32)
@@ -100,7 +108,7 @@ class SVAEEngine:
         self._plan = None
         self._anneal = 0.0
         # fused projection + log-softmax + NLL (never materialises logits): bf16 MFMA mode only
-        self.fused = (prec == PREC_BF16)
+        self.fused = prec in (PREC_BF16, PREC_SPLIT)
         self.IPAD = (self.I + 63) // 64 * 64
         self.w3b = self.w3tb = None
         self._last_fused = False
@@ -117,7 +125,7 @@ class SVAEEngine:
         # and the step does not wait for it -- it finishes under the next step's embedding / input GEMM / first
         # recurrence range, which leave most of the GPU idle, and the next step waits for it before its decoder side
         self.float_w3 = os.environ.get("SVAE_FLOAT_W3", "1") == "1"
-        self.fused_prep = os.environ.get("SVAE_FUSED_PREP", "1") == "1"
+        self.fused_prep = os.environ.get("SVAE_FUSED_PREP", "1") == "1" and not self.split
         self._in_step = False
         self._float_pending = False
         self._float_plan = None
@@ -194,20 +202,29 @@ class SVAEEngine:
             capp = (cap + 63) // 64 * 64
             self.capp = capp
             self.ws["dg4b"] = torch.zeros((cap + 1) * 4 * HP, **bf)
-            self.ws["h2b"] = torch.zeros(capp * DP, **bf)
-            self.ws["h2s"] = torch.zeros(capp * DP, **bf)
-            self.ws["h2tb"] = torch.zeros(DP * capp, **bf)
+            # (split instantiation: every bf16 image is followed by its mid and lo parts, one part stride apart)
+            m = 3 if self.split else 1
+            self.ws["h2b"] = torch.zeros(m * capp * DP, **bf)
+            self.ws["h2s"] = torch.zeros(m * capp * DP, **bf)
+            self.ws["h2tb"] = torch.zeros(m * DP * capp, **bf)
             nsm = _lib.load().svae_proj_ns_max()
             self.ws["part"] = torch.zeros(nsm * capp * 2, **f32)
             self.ws["mpart"] = torch.zeros(nsm * capp, **f32)
             self.ws["pslabs"] = torch.empty(nsm * capp * DP, **f32)
             self.ws["pslabs_side"] = torch.empty(nsm * self.IPAD * DP, **f32)
             if self.w3b is None:
-                self.wih_frags = [torch.zeros(_lib.load().svae_rowgemm_frag_elems(i), **bf) for i in (0, 1)]
-                self.mlp_frags = torch.zeros(_lib.load().svae_mlp_frag_elems(), **bf)
-                self.w3b = torch.zeros(self.IPAD * DP, **bf)
-                self.w3s = torch.zeros(self.IPAD * DP, **bf)
-                self.w3tb = torch.zeros(DP * self.IPAD, **bf)
+                self.wih_frags = [torch.zeros(m * _lib.load().svae_rowgemm_frag_elems(i), **bf) for i in (0, 1)]
+                self.mlp_frags = torch.zeros(m * _lib.load().svae_mlp_frag_elems(), **bf)
+                self.w3b = torch.zeros(m * self.IPAD * DP, **bf)
+                self.w3s = torch.zeros(m * self.IPAD * DP, **bf)
+                self.w3tb = torch.zeros(m * DP * self.IPAD, **bf)
+
+    def _ps(self, which):
+        """Part stride (elements) of the bf16 operand images: 'rows' (h2b / h2s / h2tb) or 'items' (w3b / w3s / w3tb);
+        0 in the bf16 instantiation."""
+        if not self.split:
+            return 0
+        return (self.capp if which == "rows" else self.IPAD) * DP
 
     def _ensure_logits(self):
         if self.ws["logits"].numel() < self.cap * self.IP:
@@ -217,7 +234,7 @@ class SVAEEngine:
               nsplit=1, slab_stride=0, tag=None, colsum=None):
         ev = self._tic(tag)
         _lib.call("svae_gemm", A.data_ptr(), B.data_ptr(), C.data_ptr(), _lib.ptr(bias), _lib.ptr(aux),
-                  _lib.ptr(colsum), M, N, K, lda, ldb, ldc, ldaux, al, bl, act, self.prec, nsplit, slab_stride, _stream())
+                  _lib.ptr(colsum), M, N, K, lda, ldb, ldc, ldaux, al, bl, act, self.gemm_prec, nsplit, slab_stride, _stream())
         self._toc(tag, ev)
 
     def _event(self):
@@ -295,16 +312,15 @@ class SVAEEngine:
         sp = slabs.data_ptr()
         ns = max(1, min(self.nsplit, (R + 127) // 128))
         stride = N * K + N
-        if self.prec == PREC_BF16:
+        if self.fused:
             ev = self._tic("wgrad")
             rf, ra = remap if remap is not None else (N if not dy_bf16 else (N + 7) // 8 * 8, 0)
-            fn = "svae_wgrad_cols_bf16dy" if dy_bf16 else "svae_wgrad_cols"
+            fn = "svae_wgrad_cols_bf16dy" if dy_bf16 else ("svae_wgrad_cols_prec" if self.split else "svae_wgrad_cols")
+            tail = (rf, ra, self.prec, _stream()) if fn == "svae_wgrad_cols_prec" else (rf, ra, _stream())
             if ns == 1:
-                _lib.call(fn, dY.data_ptr(), X.data_ptr(), out, out + 4 * N * K, R, N, K, ldy, ldx, 1, 0,
-                          rf, ra, _stream())
+                _lib.call(fn, dY.data_ptr(), X.data_ptr(), out, out + 4 * N * K, R, N, K, ldy, ldx, 1, 0, *tail)
             else:
-                _lib.call(fn, dY.data_ptr(), X.data_ptr(), sp, sp + 4 * N * K, R, N, K, ldy, ldx, ns, stride,
-                          rf, ra, _stream())
+                _lib.call(fn, dY.data_ptr(), X.data_ptr(), sp, sp + 4 * N * K, R, N, K, ldy, ldx, ns, stride, *tail)
                 _lib.call("svae_reduce_slabs", sp, out, stride, ns, stride, _stream())
             self._toc("wgrad", ev)
             return
@@ -353,10 +369,11 @@ class SVAEEngine:
         if self.fused and self.rowgemm:
             # W_ih fragments are built here, on the caller's stream (the GEMM is the second kernel of the step: the
             # side stream's preparation would not be ready in time), 2 us
-            _lib.call("svae_rowgemm_prep", self.P("gru.weight_ih_l0").data_ptr(), 0, self.wih_frags[0].data_ptr(), st)
+            _lib.call("svae_rowgemm_prep_prec", self.P("gru.weight_ih_l0").data_ptr(), 0, self.wih_frags[0].data_ptr(),
+                      self.prec, st)
             ev = self._tic("gi_gemm")
-            _lib.call("svae_rowgemm", w["emb"].data_ptr(), self.wih_frags[0].data_ptr(),
-                      self.P("gru.bias_ih_l0").data_ptr(), w["gi"].data_ptr(), R, 0, st)
+            _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr(), E, self.wih_frags[0].data_ptr(),
+                      self.P("gru.bias_ih_l0").data_ptr(), w["gi"].data_ptr(), R, 0, self.prec, st)
             self._toc("gi_gemm", ev)
         else:
             self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
@@ -449,12 +466,13 @@ class SVAEEngine:
                         self.P("decoder.linear2.bias").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
                         R, self.I, plan.K, w["pslabs"].data_ptr(), w["mpart"].data_ptr(), w["nll_row"].data_ptr(),
                         w["lse"].data_ptr(), w["dd1"].data_ptr()) + self._proj_sched(plan, "rows")
-                self._split_call("svae_proj_nll_fwd_dh", args, ((1, "proj_fdh_fused"), (2, "proj_fdh_finish")))
+                self._split_call("svae_proj_nll_fwd_dh", args, ((1, "proj_fdh_fused"), (2, "proj_fdh_finish")),
+                                 strides=(self._ps("rows"), self._ps("items")))
             else:
-                _lib.call("svae_proj_nll_fwd", w["h2s"].data_ptr(), self.w3b.data_ptr(), w["d1"].data_ptr(),
+                _lib.call("svae_proj_nll_fwd_split", w["h2s"].data_ptr(), self.w3b.data_ptr(), w["d1"].data_ptr(),
                           self.P("decoder.linear2.weight").data_ptr(), self.P("decoder.linear2.bias").data_ptr(),
                           plan.tgt.data_ptr(), R, self.I, plan.K, w["part"].data_ptr(), w["nll_row"].data_ptr(),
-                          w["lse"].data_ptr(), *self._proj_sched(plan, "rows"), st)
+                          w["lse"].data_ptr(), *self._proj_sched(plan, "rows"), self._ps("rows"), self._ps("items"), st)
             self._fused_grad = bool(want_grad)
             if defer_loss and want_grad and self.overlap:
                 # nothing in backward reads the scalar loss: backward() reduces it on the side stream, behind the
@@ -483,11 +501,11 @@ class SVAEEngine:
     def _mlp_fwd_rows(self, r0, r1):
         w, n = self.ws, r1 - r0
         ev = self._tic("mlp_fwd")
-        _lib.call("svae_mlp_fwd", w["hs"].data_ptr() + 4 * HP * r0, w["eps"].data_ptr() + 4 * L * r0,
+        _lib.call("svae_mlp_fwd_prec", w["hs"].data_ptr() + 4 * HP * r0, w["eps"].data_ptr() + 4 * L * r0,
                   self.mlp_frags.data_ptr(), self.P("encoder.linear1.bias").data_ptr(),
                   self.P("linear1.bias").data_ptr(), self.P("decoder.linear1.bias").data_ptr(),
                   w["enc"].data_ptr() + 4 * DP * r0, w["tmp"].data_ptr() + 8 * L * r0, w["z"].data_ptr() + 4 * L * r0,
-                  w["d1"].data_ptr() + 4 * DP * r0, w["kl_row"].data_ptr() + 4 * r0, n, _stream())
+                  w["d1"].data_ptr() + 4 * DP * r0, w["kl_row"].data_ptr() + 4 * r0, n, self.prec, _stream())
         self._toc("mlp_fwd", ev)
 
     def _decoder_rows(self, plan, r0, r1, ncu):
@@ -519,8 +537,13 @@ class SVAEEngine:
                 w["dd1"].data_ptr() + 4 * DP * r0) + self._proj_sched(plan, "rows", nx=n, ncu=ncu)
         self._split_call("svae_proj_nll_fwd_dh", args, ((1, "proj_fdh_fused"), (2, "proj_fdh_finish")))
 
-    def _split_call(self, name, args, parts):
-        """One C-ABI call covering several kernels; when profiling, one call per kernel so each is bracketed."""
+    def _split_call(self, name, args, parts, strides=None):
+        """One C-ABI call covering several kernels; when profiling, one call per kernel so each is bracketed.
+        strides: (row, item) part strides of the operand images in the split instantiation (then the `_split`
+        entry point is called)."""
+        if strides is not None and strides[0] > 0:
+            _lib.call(name + "_split", *args, sum(b for b, _ in parts), *strides, _stream())
+            return
         if self.prof is None:
             _lib.call(name, *args, sum(b for b, _ in parts), _stream())
             return
@@ -577,12 +600,13 @@ class SVAEEngine:
     def _param_prep(self, want_grad):
         """Per-step work that depends on the parameters only (they change at every optimizer step)."""
         st = _stream()
-        _lib.call("svae_mlp_prep", self.P("encoder.linear1.weight").data_ptr(), self.P("linear1.weight").data_ptr(),
-                  self.P("decoder.linear1.weight").data_ptr(), self.mlp_frags.data_ptr(), st)
+        _lib.call("svae_mlp_prep_prec", self.P("encoder.linear1.weight").data_ptr(), self.P("linear1.weight").data_ptr(),
+                  self.P("decoder.linear1.weight").data_ptr(), self.mlp_frags.data_ptr(), self.prec, st)
         if not self._w3_fresh:
             self._proj_prep_items(st)
         if want_grad and self.rowgemm:
-            _lib.call("svae_rowgemm_prep", self.P("gru.weight_ih_l0").data_ptr(), 1, self.wih_frags[1].data_ptr(), st)
+            _lib.call("svae_rowgemm_prep_prec", self.P("gru.weight_ih_l0").data_ptr(), 1, self.wih_frags[1].data_ptr(),
+                      self.prec, st)
         if want_grad:
             _lib.call("svae_transpose", self.P("gru.weight_hh_l0").data_ptr(), self.whh_t.data_ptr(), G, HP, st)
             e = self.layout.entries["item_embed.weight"]
@@ -590,16 +614,16 @@ class SVAEEngine:
         self._prepped_grad = bool(want_grad)
 
     def _proj_prep_items(self, st):
-        _lib.call("svae_proj_prep_items", self.P("decoder.linear2.weight").data_ptr(),
+        _lib.call("svae_proj_prep_items_split", self.P("decoder.linear2.weight").data_ptr(),
                   self.P("decoder.linear2.bias").data_ptr(), self.I, self.IPAD, self.w3b.data_ptr(),
-                  self.w3s.data_ptr(), self.w3tb.data_ptr(), st)
+                  self.w3s.data_ptr(), self.w3tb.data_ptr(), self._ps("items"), st)
 
     def _proj_prepare(self, R):
         """bf16 operand copies of the decoder hidden rows for the fused projection kernels."""
         w, st = self.ws, _stream()
         Rp = (R + 63) // 64 * 64
-        _lib.call("svae_proj_prep_rows", w["d1"].data_ptr(), R, Rp, w["h2b"].data_ptr(), w["h2s"].data_ptr(),
-                  w["h2tb"].data_ptr(), st)
+        _lib.call("svae_proj_prep_rows_range_split", w["d1"].data_ptr(), R, Rp, 0, Rp, w["h2b"].data_ptr(),
+                  w["h2s"].data_ptr(), w["h2tb"].data_ptr(), self._ps("rows"), st)
 
     def dense_logits(self, rows_idx=None):
         """Dense logits [n, I] for all rows of the last forward (rows_idx None) or a gathered subset
@@ -656,7 +680,8 @@ class SVAEEngine:
                         plan.occ_items.data_ptr(), plan.nocc_long, slabs.data_ptr(),
                         self.Gv("decoder.linear2.weight").data_ptr(),
                         self.Gv("decoder.linear2.bias").data_ptr()) + self._proj_sched(plan, "items")
-                self._split_call("svae_proj_nll_bwd_dw", args, ((1, "proj_dw_fused"), (2, "proj_dw_finish")))
+                self._split_call("svae_proj_nll_bwd_dw", args, ((1, "proj_dw_fused"), (2, "proj_dw_finish")),
+                                 strides=(self._ps("rows"), self._ps("items")))
 
             if self.overlap:
                 side = self._side_stream(cur=cur)
@@ -673,9 +698,9 @@ class SVAEEngine:
         # data-gradient chain: decoder.linear1 -> latent -> linear1 -> encoder.linear1
         if self.fused and self._dtmp_extra is None:
             ev = self._tic("mlp_bwd")
-            _lib.call("svae_mlp_bwd", w["dd1"].data_ptr(), w["tmp"].data_ptr(), w["eps"].data_ptr(),
+            _lib.call("svae_mlp_bwd_prec", w["dd1"].data_ptr(), w["tmp"].data_ptr(), w["eps"].data_ptr(),
                       w["enc"].data_ptr(), plan.w_kl.data_ptr(), self.mlp_frags.data_ptr(), float(anneal),
-                      w["dtmp"].data_ptr(), w["denc"].data_ptr(), w["dhs"].data_ptr(), R, st)
+                      w["dtmp"].data_ptr(), w["denc"].data_ptr(), w["dhs"].data_ptr(), R, self.prec, st)
             self._toc("mlp_bwd", ev)
         else:
             self._gemm(w["dd1"], self.P("decoder.linear1.weight"), w["dz"], R, L, DP, DP, L, L, 0, 1)
@@ -755,8 +780,8 @@ class SVAEEngine:
                     _lib.call("svae_rowgemm_bf16x", dgi.data_ptr(), ldg, self.wih_frags[1].data_ptr(),
                               w["demb"].data_ptr(), R, st)
                 else:
-                    _lib.call("svae_rowgemm_ld", dgi.data_ptr(), ldg, self.wih_frags[1].data_ptr(), None,
-                              w["demb"].data_ptr(), R, 1, st)
+                    _lib.call("svae_rowgemm_ld_prec", dgi.data_ptr(), ldg, self.wih_frags[1].data_ptr(), None,
+                              w["demb"].data_ptr(), R, 1, self.prec, st)
                 self._toc("demb_gemm", ev)
             else:
                 self._gemm(dgi, self.P("gru.weight_ih_l0"), w["demb"], R, E, G, ldg, E, E, 0, 1)

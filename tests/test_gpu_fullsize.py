@@ -1,9 +1,11 @@
 """GPU tests at BASELINE.json's full shapes (configs[2] ML-20M, configs[3] Netflix, configs[4] 1M-item catalogue).
 
 The numpy oracle cannot run these sizes in seconds, so parity here is carried by
-  * the exact-fp32 HIP path (materialised logits), itself pinned to the oracle and to the reference's golden
-    vectors at small sizes (test_gpu_parity.py), as the comparator of the fused bf16 path on identical inputs
-    (same parameters, same Philox noise: keyed by user id and timestep), and
+  * the SPLIT instantiation of the fused kernels (PREC_SPLIT: the same kernel templates at fp32-class precision,
+    pinned to the oracle and to the reference's golden vectors at the fp32 gates in test_gpu_split_parity.py) as
+    the comparator of the fused bf16 path on identical inputs (same parameters, same Philox noise: keyed by user
+    id and timestep); where the logits fit (configs[2], [3]) the exact-fp32 path with materialised logits is
+    checked against the split instantiation too, at 1e-5 / 1e-4; and
   * size-independent properties: rows of dlogits sum to zero  =>  sum_i dL/db3[i] = 0; bitwise determinism;
     top-k == a full descending sort of the same masked scores (what the reference does, nb:632).
 Tolerances (bf16 operands, fp32 accumulation): loss 1e-3 relative (the north-star gate), gradients 3e-2
@@ -37,12 +39,27 @@ def _init(eng, seed):
     return sd
 
 
-def _pair(I, users, keys, anneal=0.05):
-    """One forward+backward of the same batch in exact-fp32 mode and in fused bf16 mode."""
+def _pair(I, users, keys, anneal=0.05, dense_too=True):
+    """One forward+backward of the same batch in the split instantiation (comparator) and in fused bf16 mode;
+    dense_too: the exact-fp32 path with materialised logits must agree with the comparator at the fp32 gates."""
     import svae_cf_amd as S
     plan = S.build_plan(users, 4, user_keys=keys, device="cuda", total_items=I)
-    ref = S.SVAEEngine(I, device="cuda", prec=S.PREC_FP32)
+    ref = S.SVAEEngine(I, device="cuda", prec=S.PREC_SPLIT)
     sd = _init(ref, 11)
+    if dense_too:
+        dense = S.SVAEEngine(I, device="cuda", prec=S.PREC_FP32)
+        dense.load_state_dict(sd)
+        l_dense = float(dense.forward(plan, anneal, seed=7, step=3)[0])
+        dense.backward()
+        l_split = float(ref.forward(plan, anneal, seed=7, step=3)[0])
+        ref.backward()
+        torch.cuda.synchronize()
+        assert abs(l_split - l_dense) <= 1e-5 * abs(l_dense), (l_split, l_dense)
+        gd, gs = dense.grad_dict(), ref.grad_dict()
+        for k in gd:
+            assert _l2(gs[k], gd[k]) <= 1e-4, ("split vs exact fp32", k, _l2(gs[k], gd[k]))
+        del dense, gd, gs
+        torch.cuda.empty_cache()
     fast = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
     fast.load_state_dict(sd)
     l_ref = float(ref.forward(plan, anneal, seed=7, step=3)[0])
@@ -103,7 +120,7 @@ def test_large_catalogue_one_million_items():
     users = [rs.choice(I, size=rs.randint(3, 14), replace=False) for _ in range(8)]
     plan, ref, fast, l_ref, l_fast = _pair(I, users, np.arange(8))
     _check_pair(ref, fast, l_ref, l_fast)
-    # scoring: loss-only sweep (bf16) against the exact path, and top-100 against a full sort of the same scores
+    # scoring: loss-only sweep (bf16) against the split instantiation, and top-100 against a full sort of the same scores
     l_s_ref, idx_ref, val_ref, last_ref = ref.score(plan, 100, seed=7, step=3)
     l_s_ref = float(l_s_ref[0])
     l_s_fast, idx_fast, val_fast, last_fast = fast.score(plan, 100, seed=7, step=3)

@@ -283,10 +283,14 @@ def test_bf16_mode_train_steps_vs_reference(golden_dir):
         plan = S.build_plan([g["items%d" % u]], 4, device="cuda", total_items=I)
         eps = torch.from_numpy(S.pack_rows(plan, [g["eps%d" % (b - 1)]], 64)).cuda()
         losses.append(float(eng.train_step(plan, O.anneal_for_batch(b), eps=eps)[0]))
-    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
+    # north_star's loss gate (1e-3); parameters: bf16 operands (2^-9 relative) put the gradients at ~1e-2 and the
+    # parameters after 12 Adam steps at 1e-4 .. 3e-3 rel-L2 (tools/precision_report.py) -- a stated exception to
+    # the 1e-4 parameter gate, which the SAME kernels meet in their split instantiation
+    # (tests/test_gpu_split_parity.py::test_split_train_steps_vs_reference_train).  Gate: 5e-3.
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-3)
     sd = eng.state_dict()
     for k in O.PARAM_NAMES:
-        assert _l2(sd[k].cpu().numpy(), g["final/" + k]) <= 1e-2, k
+        assert _l2(sd[k].cpu().numpy(), g["final/" + k]) <= 5e-3, k
 
 
 def test_bf16_mode_larger_batch_vs_oracle():

@@ -24,7 +24,7 @@ def sd(p):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()}
 
 
-for prec, pname in ((0, "fp32"), (1, "bf16")):
+for prec, pname in ((0, "fp32"), (2, "split"), (1, "bf16")):
     print("=== prec", pname)
     g = np.load(os.path.join(G, "fwd_bwd_I97_k4.npz"))
     I, seed, anneal = int(g["total_items"]), int(g["seed"]), float(g["anneal"])
