@@ -78,8 +78,9 @@ constexpr int YIMG_BYTES = BY * KP * 2;        // 20480
 constexpr int TIMG_BYTES = KP * BY * 2;        // 20480
 constexpr int STAGE_BYTES = YIMG_BYTES + TIMG_BYTES;
 constexpr int NCHUNK = YIMG_BYTES / 16;        // 1280 chunks per image
-constexpr int NSTAGE = 3;
-constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES + 8 * 32 * 4;   // + per-wave rescale factors
+constexpr int NSTAGE = 3;                      // loss-only sweep (FWD) and the split instantiation's three parts
+constexpr int NSTAGE_P = 4;                    // software-pipelined sweeps (FDH / DW): the whole 160 KiB of the CU
+constexpr int LDS_BYTES = NSTAGE_P * STAGE_BYTES;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
@@ -207,10 +208,11 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     int rb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) rb[q] = YIMG_BYTES + li * (BY * 2) + 16 * ((2 * q + lh) ^ sw2);
-    float* fs = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES) + wave * 32;
 
     // Running stabiliser of the softmax (FDH / FWD), shared by both instantiations: see the file header.
-    auto stabilise = [&](f32x16& c1) {
+    // Returns the factor by which the lane's row was rescaled (1 when the stabiliser stayed).
+    auto stabilise = [&](f32x16& c1) -> float {
+    float f_ret = 1.0f;
     if (MODE != MODE_DW) {
         float tm = fmaxf(c1[0], c1[1]);
 #pragma unroll
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
             const float mq = need ? -((hif + sv_bf2f(lo)) + sv_bf2f(lo2)) : m_eff;
             const float delta = m_eff - mq;          // <= 0 (0 for rows left alone)
             const float f = __builtin_amdgcn_exp2f(delta);
+            f_ret = f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) c1[r] += delta;
             if (need && lh == 1) {
@@ -241,26 +244,175 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
             if (MODE == MODE_FWD) {
                 l_run *= f;
             } else {
-                // Z rows are x = (r&3) + 8 (r>>2) + 4 lh: fetch the factors of those rows through LDS
-                if (lh == 0) fs[li] = f;
-                asm volatile("" ::: "memory");      // read by other lanes: keep the compiler from reordering
-                __builtin_amdgcn_wave_barrier();
+                // Z rows are x = (r&3) + 8 (r>>2) + 4 lh: the factor of row x sits in lane x (both halves hold it)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 fv = *reinterpret_cast<const float4*>(fs + 8 * g + 4 * lh);
+                    const float f0 = __shfl(f, 8 * g + 4 * lh + 0, 64), f1 = __shfl(f, 8 * g + 4 * lh + 1, 64);
+                    const float f2 = __shfl(f, 8 * g + 4 * lh + 2, 64), f3 = __shfl(f, 8 * g + 4 * lh + 3, 64);
 #pragma unroll
                     for (int n = 0; n < NT2; ++n) {
-                        Z[n][4 * g + 0] *= fv.x; Z[n][4 * g + 1] *= fv.y;
-                        Z[n][4 * g + 2] *= fv.z; Z[n][4 * g + 3] *= fv.w;
+                        Z[n][4 * g + 0] *= f0; Z[n][4 * g + 1] *= f1;
+                        Z[n][4 * g + 2] *= f2; Z[n][4 * g + 3] *= f3;
                     }
                 }
             }
             thr = RESCALE_THR;
         }
     }
+    return f_ret;
     };
 
-    if constexpr (!SPLIT) {
+    if constexpr (!SPLIT && MODE != MODE_FWD) {
+    // ---- software-pipelined sweep (FDH / DW) ------------------------------------------------------------------
+    // Sub-tiles (32 y rows; two per tile) are numbered k = 0 .. 2n-1.  GEMM2 of sub-tile k runs one phase late,
+    // TOGETHER with the vector work (stabiliser check, exp2, bf16 pack) of sub-tile k+1:
+    //     iteration k:   A  GEMM1(k+1)                      10 MFMAs, LDS fragment reads, LDS-DMA issue in the gaps
+    //                    B  GEMM2(k)  ||  exp/pack(k+1)     10 MFMAs with 2 v_exp + 1 v_cvt_pk in each gap
+    // so every wave's own stream keeps the matrix pipe fed while its vector work issues (an MFMA holds the SIMD's
+    // vector issue for 8 of its 32 cycles: 24 cycles of vector issue per MFMA are free).  Before, a wave alternated
+    // MFMA-only and VALU-only phases and relied on its SIMD partner being in the other kind -- which the per-tile
+    // barrier prevented: partners ran in lockstep, matrix pipe ~60 % busy inside the loop.
+    // Fragments live in rotating windows of W registers sets, refilled right behind the MFMA that consumed a slot:
+    // the Y window runs 5 fragments ahead through GEMM1(k+1), GEMM1(k+2), ...; the Y^T window likewise through
+    // GEMM2(k), GEMM2(k+1).  LDS: four stages (the CU's 160 KiB); tile j (relative) lives in stage j & 3, is first
+    // read at the end of iteration 2j-2 and last read in iteration 2j+1; the one barrier of a tile closes iteration
+    // 2j+1.  Behind it tile j+2 has landed everywhere (each wave waits for its own pieces, tile j+3's stay in
+    // flight) and stage j & 3 is free: tile j+4 is issued into it during the next tile's iterations, piece by piece
+    // between MFMAs.
+    constexpr int W = 5;
+    const int ntile = t_end - t_begin;
+    if (ntile > 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < ntile) SV_STAGE_ALL(t_begin + j, j)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#define SV_YA(st_, sub_, s_) \
+    (*reinterpret_cast<const bf16x8*>((st_) + (sub_) * (32 * KP * 2) + 64 * ((s_) >> 1) + (((s_) & 1) ? ra1 : ra0)))
+#define SV_YB(st_, sub_, i_) \
+    (*reinterpret_cast<const bf16x8*>((st_) + ((i_) >> 1) * (32 * BY * 2) + rb[2 * (sub_) + ((i_) & 1)]))
+#define SV_MFMA_DS                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        bf16x8 fa[W], fb[W], pa[2];
+        f32x16 c1;
+        // prologue: GEMM1(0), its vector work, and the two windows
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c1[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SV_YA(smem, 0, s), xf[s], c1, 0, 0, 0);
+            stabilise(c1);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint4 u;
+                u.x = pack_bf16(__builtin_amdgcn_exp2f(c1[8 * s2 + 0]), __builtin_amdgcn_exp2f(c1[8 * s2 + 1]));
+                u.y = pack_bf16(__builtin_amdgcn_exp2f(c1[8 * s2 + 2]), __builtin_amdgcn_exp2f(c1[8 * s2 + 3]));
+                u.z = pack_bf16(__builtin_amdgcn_exp2f(c1[8 * s2 + 4]), __builtin_amdgcn_exp2f(c1[8 * s2 + 5]));
+                u.w = pack_bf16(__builtin_amdgcn_exp2f(c1[8 * s2 + 6]), __builtin_amdgcn_exp2f(c1[8 * s2 + 7]));
+                pa[s2] = *reinterpret_cast<bf16x8*>(&u);
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w) { fa[w] = SV_YA(smem, 1, w); fb[w] = SV_YB(smem, 0, w); }
+        }
+#ifdef SV_PROJ_TIMING
+        const unsigned long long blk_rt0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long blk_c0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int j = 0; j < ntile; ++j) {
+            const char* st = smem + (j & 3) * STAGE_BYTES;
+            const char* stn = smem + ((j + 1) & 3) * STAGE_BYTES;
+            const bool more = j + 1 < ntile;              // a next tile exists
+            const bool dma = j + 3 < ntile;               // tile j+3 is issued during this tile's iterations
+            const char* dy = Yg + (size_t)(t_begin + j + 3) * (BY * KP * 2);
+            const char* dt = Tg + (size_t)(t_begin + j + 3) * (BY * 2);
+            char* dl = smem + ((j + 3) & 3) * STAGE_BYTES + wave * 1024;
+#define SV_DMA(q_) if (dma && (q_) < npiece) SV_PIECE(q_, dy, dt, dl)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const bool has_next = sub == 0 || more;   // sub-tile k+1 exists
+                // ---- A: GEMM1(k+1); the Y window moves on through sub-tile k+1 and into sub-tile k+2
+                const char* a1 = sub == 0 ? st : stn;     // stage of sub-tile k+1 (its sub index: 1 - sub)
+                if (has_next) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c1[r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS1; ++s) {
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % W], xf[s], c1, 0, 0, 0);
+                        fa[s % W] = s < W ? SV_YA(a1, 1 - sub, s + W) : SV_YA(stn, sub, s - W);
+                        SV_MFMA_DS
+                        if (s == 2) SV_DMA(2 * sub)
+                        if (s == 6) SV_DMA(2 * sub + 1)
+                    }
+                }
+                // ---- B: GEMM2(k) beside the vector work of sub-tile k+1; the Y^T window moves on
+                // Gap i = MFMA i, one fragment read, and for i = 1..8 two v_exp + one v_cvt_pk of sub-tile k+1 (gap 0
+                // stays bare: the logits come out of GEMM1's last MFMA, still in flight) and one v_max3 of the
+                // stabiliser check.  The check itself comes AFTER the phase: a raise is only needed before a logit
+                // exceeds the stabiliser by 2^127, the threshold is 2^16, so the rows that crossed it in this
+                // sub-tile are raised now -- Z holds GEMM2(k) by then -- and their sixteen exponentials redone.
+                const char* b1 = sub == 0 ? st : stn;     // stage of sub-tile k+1's Y^T fragments
+                {
+                    unsigned pw[8];
+                    float tm = -3.0e38f;
+#pragma unroll
+                    for (int i = 0; i < KS1; ++i) {
+                        // Pin the order of the gaps.  The MFMAs, v_exp and v_cvt_pk below are pure values to the
+                        // compiler, which otherwise gathers the sixteen v_exp in front of the ten MFMAs; an empty asm
+                        // that "rewrites" this gap's inputs (the MFMA's A operand, the two logits) and the gap
+                        // before's output is a point they cannot cross.  It emits no instruction.
+                        if (i == 0) asm volatile("" : "+v"(pa[0]));
+                        else if (i == 1) asm volatile("" : "+v"(pa[1]), "+v"(c1[0]), "+v"(c1[1]));
+                        else if (i <= 8) asm volatile("" : "+v"(pa[i & 1]), "+v"(c1[2 * i - 2]), "+v"(c1[2 * i - 1]), "+v"(pw[i - 2]));
+                        else asm volatile("" : "+v"(pa[i & 1]), "+v"(pw[7]));
+                        Z[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i & 1], fb[i % W], Z[i >> 1], 0, 0, 0);
+                        fb[i % W] = i < W ? SV_YB(st, sub, i + W) : SV_YB(b1, 1 - sub, i - W);
+                        if (i >= 1 && i <= 8) {     // (without a next sub-tile c1 holds stale finite numbers: unused)
+                            const float l0 = c1[2 * i - 2], l1 = c1[2 * i - 1];
+                            pw[i - 1] = pack_bf16(__builtin_amdgcn_exp2f(l0), __builtin_amdgcn_exp2f(l1));
+                            if (MODE != MODE_DW) tm = fmaxf(tm, fmaxf(l0, l1));
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (i >= 1 && i <= 8) {
+                            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, MODE != MODE_DW ? 2 : 1, 0);
+                        }
+                        if (sub == 0 && i == 8) SV_DMA(4)
+                        if (sub == 0 && i == 9) SV_DMA(5)
+                    }
+                    if (MODE != MODE_DW && has_next && __any(tm > thr)) {
+                        stabilise(c1);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            pw[q] = pack_bf16(__builtin_amdgcn_exp2f(c1[2 * q]), __builtin_amdgcn_exp2f(c1[2 * q + 1]));
+                    }
+                    pa[0] = __builtin_bit_cast(bf16x8, (uint4){pw[0], pw[1], pw[2], pw[3]});
+                    pa[1] = __builtin_bit_cast(bf16x8, (uint4){pw[4], pw[5], pw[6], pw[7]});
+                }
+            }
+            // the one barrier of the tile (see above)
+            if (!dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NIMG) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIMG) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+#ifdef SV_PROJ_TIMING
+        if (lane == 0 && wave == 0 && blockIdx.x < 4096) {
+            g_proj_blk[MODE][blockIdx.x][0] = blk_rt0;
+            g_proj_blk[MODE][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+            g_proj_blk[MODE][blockIdx.x][2] = __builtin_amdgcn_s_memtime() - blk_c0;
+            g_proj_blk[MODE][blockIdx.x][3] = (unsigned long long)ntile;
+        }
+#endif
+#undef SV_DMA
+#undef SV_YA
+#undef SV_YB
+#undef SV_MFMA_DS
+    }
+    } else if constexpr (!SPLIT) {
     // Three LDS stages; tile t lives in stage (t - t_begin) % 3.  An LDS-DMA piece takes 1-2 us from issue to
     // landed under load (about one tile), so a tile's pieces are issued between one and two tiles ahead:
     // pieces 0,1 of tile t+3 behind the barrier of tile t (into tile t's stage: every wave made its last read of

@@ -1,9 +1,19 @@
 #!/bin/bash
-# A/B of environment knobs: tools/ab.sh "VAR=a" "VAR=b" ... ; each runs bench.py (no CPU baseline)
-cd ${GRAFT_REPO_ROOT:-.}
-for kv in "$@"; do
-  env_kv=$(echo $kv | tr ',' ' ')
-  out=$(export $env_kv; timeout -k 10 120 python bench.py --no-cpu-baseline --steps 40 --warmup 8 2>/dev/null) || exit 1
-  echo "$out" | python -c "
-import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$kv', round(d['value']), round(d['ms_per_step'],4), round(d.get('host_enqueue_ms_per_step',0),3), {k: round(v,4) for k,v in d['kernel_ms'].items()}, d['config'].get('side_stream'))"
+# A/B of two builds of the kernel library on one box: bench.py with the in-tree library and with SVAE_HIP_LIB=$1,
+# alternating, $2 rounds.  Usage (via gpurun): bash tools/ab.sh svae_cf_amd/csrc/exp/lib_base.so 2 [bench args]
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$ROOT" || exit 1
+ALT=$1; N=${2:-2}; shift 2
+mkdir -p gpurun_out
+for i in $(seq 1 $N); do
+  timeout -k 10 200 python bench.py --no-cpu-baseline --repeats 3 "$@" > gpurun_out/ab_new_$i.json 2> gpurun_out/ab_new_$i.err || { tail -20 gpurun_out/ab_new_$i.err; exit 1; }
+  SVAE_HIP_LIB=$ROOT/$ALT timeout -k 10 200 python bench.py --no-cpu-baseline --repeats 3 "$@" > gpurun_out/ab_alt_$i.json 2> gpurun_out/ab_alt_$i.err || { tail -20 gpurun_out/ab_alt_$i.err; exit 2; }
+  python3 - <<PY
+import json
+for tag in ("new","alt"):
+    d=json.load(open("gpurun_out/ab_%s_$i.json"%tag))
+    k=d["kernel_ms"]
+    print("$i", tag, "seq/s %.0f  ms/step %.4f (regions %s)  fdh %.4f dw %.4f gru %.3f/%.3f wgrad %.3f" % (d["value"], d["ms_per_step"], d["ms_per_step_regions"]["median"], k.get("proj_fdh_fused",0), k.get("proj_dw_fused",0), k.get("gru_fwd",0), k.get("gru_bwd",0), k.get("wgrad",0)))
+PY
 done
