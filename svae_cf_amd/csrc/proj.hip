@@ -113,6 +113,16 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// ds_read_b64_tr_b16 (gfx950): a 16-lane group reads a block of 4 rows x 16 columns of 16-bit elements; lane 4q + p
+// supplies the address of row q, columns 4p .. 4p+3; lane i receives column i of the four rows.  EXEC must be full.
+typedef short s4v __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ s4v tr_read(unsigned addr) {
+    s4v v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
 // lo part of a packed bf16 pair: RNE(a - hi(a)), RNE(b - hi(b))
 __device__ __forceinline__ unsigned pack_lo(float a, float b, unsigned hw) {
     return pack_bf16(a - __uint_as_float(hw << 16), b - __uint_as_float(hw & 0xFFFF0000u));
@@ -265,32 +275,92 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     if constexpr (!SPLIT && MODE != MODE_FWD) {
     // ---- software-pipelined sweep (FDH / DW) ------------------------------------------------------------------
     // Sub-tiles (32 y rows; two per tile) are numbered k = 0 .. 2n-1.  GEMM2 of sub-tile k runs one phase late,
-    // TOGETHER with the vector work (stabiliser check, exp2, bf16 pack) of sub-tile k+1:
+    // TOGETHER with the vector work (exp2, bf16 pack, stabiliser maximum) of sub-tile k+1:
     //     iteration k:   A  GEMM1(k+1)                      10 MFMAs, LDS fragment reads, LDS-DMA issue in the gaps
     //                    B  GEMM2(k)  ||  exp/pack(k+1)     10 MFMAs with 2 v_exp + 1 v_cvt_pk in each gap
     // so every wave's own stream keeps the matrix pipe fed while its vector work issues (an MFMA holds the SIMD's
     // vector issue for 8 of its 32 cycles: 24 cycles of vector issue per MFMA are free).  Before, a wave alternated
     // MFMA-only and VALU-only phases and relied on its SIMD partner being in the other kind -- which the per-tile
     // barrier prevented: partners ran in lockstep, matrix pipe ~60 % busy inside the loop.
-    // Fragments live in rotating windows of W registers sets, refilled right behind the MFMA that consumed a slot:
-    // the Y window runs 5 fragments ahead through GEMM1(k+1), GEMM1(k+2), ...; the Y^T window likewise through
-    // GEMM2(k), GEMM2(k+1).  LDS: four stages (the CU's 160 KiB); tile j (relative) lives in stage j & 3, is first
-    // read at the end of iteration 2j-2 and last read in iteration 2j+1; the one barrier of a tile closes iteration
-    // 2j+1.  Behind it tile j+2 has landed everywhere (each wave waits for its own pieces, tile j+3's stay in
-    // flight) and stage j & 3 is free: tile j+4 is issued into it during the next tile's iterations, piece by piece
-    // between MFMAs.
-    constexpr int W = 5;
+    //
+    // ONE image per tile.  GEMM2's B operand is Y transposed; it is read straight out of the row-major Y image with
+    // ds_read_b64_tr_b16 (gfx950: a 16-lane group reads a block of 4 rows x 16 columns and every lane gets one
+    // column of it): the k-order of a converted accumulator -- element j of lane half lh is y = 16 s2 + 8 (j>>2) +
+    // 4 lh + (j&3) -- is two such blocks of four consecutive rows, so a fragment is two 8-byte transposed reads, and
+    // the image's chunk swizzle (position c ^ ((row >> 2) & 3), constant over a block's rows) keeps them
+    // conflict-free: the four rows' 64-byte runs fall into the four quarters of the 256-byte bank window.  The
+    // transposed copies (w3tb / h2tb) are not staged at all: half the L2 -> LDS traffic and half the LDS-DMA
+    // instructions of the two-image form, whose loop ran at 3500 (FDH) / 3100 (DW) cycles per tile against the
+    // matrix pipe's 2560 -- it was the fill, not the arithmetic, that set its pace.
+    //
+    // Fragments live in rotating windows of W register sets, refilled right behind the MFMA that consumed a slot:
+    // the Y window runs W fragments ahead through GEMM1(k+1), GEMM1(k+2), ...; the Y^T window likewise through
+    // GEMM2(k), GEMM2(k+1).  LDS: NSTP stages of 20 KiB; tile j (relative) lives in stage j % NSTP, is first read at
+    // the end of iteration 2j-2 and last read in iteration 2j+1; the one barrier of a tile closes iteration 2j+1.
+    // Behind it tile j+2 has landed everywhere (each wave waits for its own pieces; those of the tiles behind stay
+    // in flight) and stage j % NSTP is free: tile j+NSTP is issued into it during the next tile's iterations, piece
+    // by piece between MFMAs.
+    //
+    // (Tried: a stagger -- waves 4..7 taking the tile's barrier one phase earlier in program order, so that SIMD
+    //  partners run A beside B: 3297 -> 3202 cycles per tile in the DW sweep, and 95 spilled registers in the FDH one,
+    //  whose mid-iteration barrier keeps the logits alive across it; a barrier every other tile: 3194.  Not kept.
+    //  Timing builds without v_exp (-160 cycles), without LDS-DMA in the loop (0) and without the LDS drain in front
+    //  of the barrier (0) say the remaining 25 % over the matrix pipe's 2560 cycles per tile is neither of those.)
+    constexpr int W = 4;
+    constexpr int NSTP = 6;                       // stages; tiles j+3 .. j+NSTP-1 are in flight behind tile j's barrier
+    constexpr int PSTAGE = YIMG_BYTES;
     const int ntile = t_end - t_begin;
+    const int npc = wave < 4 ? 3 : 2;             // this wave's pieces of a tile (20 pieces of 1 KiB over 8 waves)
     if (ntile > 0) {
+#define SV_PIECE1(q_, ybase_, lbase_) glds16((ybase_) + offY[q_], (lbase_) + 8192 * (q_));
+        // wait until all but the youngest c_ tiles' pieces of this wave have landed (c_ uniform, 0 .. NSTP-3)
+#define SV_WAIT_TILES(c_)                                                                    \
+    {                                                                                        \
+        const int n_ = (c_) * npc;                                                           \
+        if (n_ >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                         \
+        else if (n_ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                    \
+        else if (n_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                    \
+        else if (n_ == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                    \
+        else if (n_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 \
+    }
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (j < ntile) SV_STAGE_ALL(t_begin + j, j)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int j = 0; j < NSTP - 1; ++j)
+            if (j < ntile) {
+                const char* yb_ = Yg + (size_t)(t_begin + j) * (BY * KP * 2);
+                char* ly_ = smem + j * PSTAGE + wave * 1024;
+#pragma unroll
+                for (int q_ = 0; q_ < 3; ++q_)
+                    if (q_ < npc) SV_PIECE1(q_, yb_, ly_)
+            }
+        {
+            const int issued = ntile < NSTP - 1 ? ntile : NSTP - 1;
+            SV_WAIT_TILES(issued > 3 ? issued - 3 : 0)          // tiles 0 .. 2 landed
+        }
         __syncthreads();
+        // transposed fragment reads: lane 4q + p of 16-lane group gq supplies row q, columns 4p .. 4p+3 of its block
+        int tb[2];
+        {
+            const int gq = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+            const int cc = 2 * (gq & 1) + (p4 >> 1);          // 16-byte chunk inside the n tile's 64-byte run
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                tb[h] = (8 * h + 4 * lh + q) * (KP * 2) + 16 * (cc ^ (2 * h + lh)) + 8 * (p4 & 1);
+        }
 #define SV_YA(st_, sub_, s_) \
     (*reinterpret_cast<const bf16x8*>((st_) + (sub_) * (32 * KP * 2) + 64 * ((s_) >> 1) + (((s_) & 1) ? ra1 : ra0)))
+        // (st_: the per-lane LDS byte addresses {stage base + tb[0], stage base + tb[1]} of a stage, so that every read
+        //  is one base register + an immediate offset)
+        // The read is inline asm, not __builtin_amdgcn_ds_read_tr16_b64: behind the builtin the compiler puts an
+        // s_waitcnt vmcnt(0) in front of the first read of every phase (an LDS read it cannot tell apart from the
+        // LDS-DMA writes in flight), which drains the whole prefetch ring twice per tile.  The price: the compiler
+        // does not count these reads, so the waits are ours -- LDS returns in order, a fragment is consumed W = 4 gaps
+        // (= 6 later reads) after its two reads were issued: s_waitcnt lgkmcnt(6) in front of each MFMA of GEMM2.
+#define SV_TR(st_, sub_, i_, h_)                                                                          \
+    tr_read<(sub_) * (32 * KP * 2) + ((i_) & 1) * (16 * KP * 2) + 64 * ((i_) >> 1)>((st_)[h_])
 #define SV_YB(st_, sub_, i_) \
-    (*reinterpret_cast<const bf16x8*>((st_) + ((i_) >> 1) * (32 * BY * 2) + rb[2 * (sub_) + ((i_) & 1)]))
+    __builtin_shufflevector(SV_TR(st_, sub_, i_, 0), SV_TR(st_, sub_, i_, 1), 0, 1, 2, 3, 4, 5, 6, 7)
+        const unsigned lds0 = (unsigned)(size_t)smem;
 #define SV_MFMA_DS                                     \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -312,22 +382,55 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                 u.w = pack_bf16(__builtin_amdgcn_exp2f(c1[8 * s2 + 6]), __builtin_amdgcn_exp2f(c1[8 * s2 + 7]));
                 pa[s2] = *reinterpret_cast<bf16x8*>(&u);
             }
+            const unsigned t0_[2] = {lds0 + (unsigned)tb[0], lds0 + (unsigned)tb[1]};
 #pragma unroll
-            for (int w = 0; w < W; ++w) { fa[w] = SV_YA(smem, 1, w); fb[w] = SV_YB(smem, 0, w); }
+            for (int w = 0; w < W; ++w) fa[w] = SV_YA(smem, 1, w);
+            static_assert(W == 4 && (2 * KS1) % W == 0, "the prologue, the waits and the slot numbering below assume this");
+            fb[0] = SV_YB(t0_, 0, 0); fb[1] = SV_YB(t0_, 0, 1); fb[2] = SV_YB(t0_, 0, 2); fb[3] = SV_YB(t0_, 0, 3);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
         }
 #ifdef SV_PROJ_TIMING
         const unsigned long long blk_rt0 = __builtin_amdgcn_s_memrealtime();
         const unsigned long long blk_c0 = __builtin_amdgcn_s_memtime();
 #endif
+        // the tile's barrier: tile j+2 must have landed; the tiles issued behind it (up to j+NSTP-1) stay in flight
+#define SV_TILE_BARRIER                                                             \
+    {                                                                               \
+        const int last_ = j + NSTP - 1 < ntile ? j + NSTP - 1 : ntile - 1;          \
+        SV_WAIT_TILES(last_ > j + 2 ? last_ - (j + 2) : 0)                          \
+        SV_LGKM0_INSN                                                               \
+        SV_BARRIER_INSN                                                             \
+        asm volatile("" ::: "memory");                                              \
+    }
+#if defined(SV_EXP_NOBAR)     // (timing experiments only: no barrier / a barrier every other tile / no LDS drain)
+#define SV_BARRIER_INSN
+#elif defined(SV_EXP_BAR2)
+#define SV_BARRIER_INSN if (j & 1) __builtin_amdgcn_s_barrier();
+#else
+#define SV_BARRIER_INSN __builtin_amdgcn_s_barrier();
+#endif
+#ifdef SV_EXP_NOLGKM
+#define SV_LGKM0_INSN
+#else
+#define SV_LGKM0_INSN asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        int sj = 0;                                       // stage of tile j
         for (int j = 0; j < ntile; ++j) {
-            const char* st = smem + (j & 3) * STAGE_BYTES;
-            const char* stn = smem + ((j + 1) & 3) * STAGE_BYTES;
+            const int sn = sj + 1 == NSTP ? 0 : sj + 1;   // stage of tile j+1
+            const int sd = sj == 0 ? NSTP - 1 : sj - 1;   // stage of tile j-1 = stage of tile j+NSTP-1
+            const char* st = smem + sj * PSTAGE;
+            const char* stn = smem + sn * PSTAGE;
+            const unsigned tst[2] = {lds0 + (unsigned)(sj * PSTAGE + tb[0]), lds0 + (unsigned)(sj * PSTAGE + tb[1])};
+            const unsigned tsn[2] = {lds0 + (unsigned)(sn * PSTAGE + tb[0]), lds0 + (unsigned)(sn * PSTAGE + tb[1])};
             const bool more = j + 1 < ntile;              // a next tile exists
-            const bool dma = j + 3 < ntile;               // tile j+3 is issued during this tile's iterations
-            const char* dy = Yg + (size_t)(t_begin + j + 3) * (BY * KP * 2);
-            const char* dt = Tg + (size_t)(t_begin + j + 3) * (BY * 2);
-            char* dl = smem + ((j + 3) & 3) * STAGE_BYTES + wave * 1024;
-#define SV_DMA(q_) if (dma && (q_) < npiece) SV_PIECE(q_, dy, dt, dl)
+            const bool dma = j + NSTP - 1 < ntile;        // tile j+NSTP-1 is issued during this tile's iterations
+            const char* dy = Yg + (size_t)(t_begin + j + NSTP - 1) * (BY * KP * 2);
+            char* dl = smem + sd * PSTAGE + wave * 1024;
+#ifdef SV_EXP_NODMA      // timing experiment only (wrong results): no LDS-DMA inside the loop
+#define SV_DMA(q_) {}
+#else
+#define SV_DMA(q_) if (dma && (q_) < npc) SV_PIECE1(q_, dy, dl)
+#endif
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const bool has_next = sub == 0 || more;   // sub-tile k+1 exists
@@ -338,49 +441,67 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                     for (int r = 0; r < 16; ++r) c1[r] = 0.f;
 #pragma unroll
                     for (int s = 0; s < KS1; ++s) {
-                        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % W], xf[s], c1, 0, 0, 0);
-                        fa[s % W] = s < W ? SV_YA(a1, 1 - sub, s + W) : SV_YA(stn, sub, s - W);
+                        // (slot of fragment s of this phase: the window turns through the 2 KS1 fragments of a tile's
+                        //  two phases, and W divides 2 KS1, not KS1)
+                        const int sl = (KS1 * sub + s) % W;
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sl], xf[s], c1, 0, 0, 0);
+                        fa[sl] = s + W < KS1 ? SV_YA(a1, 1 - sub, s + W) : SV_YA(stn, sub, s + W - KS1);
                         SV_MFMA_DS
-                        if (s == 2) SV_DMA(2 * sub)
-                        if (s == 6) SV_DMA(2 * sub + 1)
+                        if (s == 2) SV_DMA(sub)
+                        if (sub == 0 && s == 6) SV_DMA(2)
                     }
                 }
                 // ---- B: GEMM2(k) beside the vector work of sub-tile k+1; the Y^T window moves on
-                // Gap i = MFMA i, one fragment read, and for i = 1..8 two v_exp + one v_cvt_pk of sub-tile k+1 (gap 0
-                // stays bare: the logits come out of GEMM1's last MFMA, still in flight) and one v_max3 of the
-                // stabiliser check.  The check itself comes AFTER the phase: a raise is only needed before a logit
-                // exceeds the stabiliser by 2^127, the threshold is 2^16, so the rows that crossed it in this
-                // sub-tile are raised now -- Z holds GEMM2(k) by then -- and their sixteen exponentials redone.
-                const char* b1 = sub == 0 ? st : stn;     // stage of sub-tile k+1's Y^T fragments
+                // Gap i = MFMA i, one transposed fragment (two reads), and for i = 1..8 two v_exp + one v_cvt_pk of
+                // sub-tile k+1 (gap 0 stays bare: the logits come out of GEMM1's last MFMA, still in flight) and one
+                // v_max3 of the stabiliser check.  The check itself comes AFTER the phase: a raise is only needed
+                // before a logit exceeds the stabiliser by 2^127, the threshold is 2^16, so the rows that crossed it
+                // in this sub-tile are raised now -- Z holds GEMM2(k) by then -- and their sixteen exponentials redone.
                 {
                     unsigned pw[8];
                     float tm = -3.0e38f;
-#pragma unroll
-                    for (int i = 0; i < KS1; ++i) {
-                        // Pin the order of the gaps.  The MFMAs, v_exp and v_cvt_pk below are pure values to the
-                        // compiler, which otherwise gathers the sixteen v_exp in front of the ten MFMAs; an empty asm
-                        // that "rewrites" this gap's inputs (the MFMA's A operand, the two logits) and the gap
-                        // before's output is a point they cannot cross.  It emits no instruction.
-                        if (i == 0) asm volatile("" : "+v"(pa[0]));
-                        else if (i == 1) asm volatile("" : "+v"(pa[1]), "+v"(c1[0]), "+v"(c1[1]));
-                        else if (i <= 8) asm volatile("" : "+v"(pa[i & 1]), "+v"(c1[2 * i - 2]), "+v"(c1[2 * i - 1]), "+v"(pw[i - 2]));
-                        else asm volatile("" : "+v"(pa[i & 1]), "+v"(pw[7]));
-                        Z[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i & 1], fb[i % W], Z[i >> 1], 0, 0, 0);
-                        fb[i % W] = i < W ? SV_YB(st, sub, i + W) : SV_YB(b1, 1 - sub, i - W);
-                        if (i >= 1 && i <= 8) {     // (without a next sub-tile c1 holds stale finite numbers: unused)
-                            const float l0 = c1[2 * i - 2], l1 = c1[2 * i - 1];
-                            pw[i - 1] = pack_bf16(__builtin_amdgcn_exp2f(l0), __builtin_amdgcn_exp2f(l1));
-                            if (MODE != MODE_DW) tm = fmaxf(tm, fmaxf(l0, l1));
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (i >= 1 && i <= 8) {
-                            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, MODE != MODE_DW ? 2 : 1, 0);
-                        }
-                        if (sub == 0 && i == 8) SV_DMA(4)
-                        if (sub == 0 && i == 9) SV_DMA(5)
+                    // Pin the order of the gaps.  The MFMAs, v_exp and v_cvt_pk are pure values to the compiler,
+                    // which otherwise gathers the sixteen v_exp in front of the ten MFMAs; an empty asm that
+                    // "rewrites" a gap's inputs (the MFMA's A operand, the two logits) and the gap before's output is
+                    // a point they cannot cross.  It emits no instruction.  (Literal gap numbers: the transposed
+                    // reads take their offsets as immediates.)
+#ifdef SV_EXP_NOEXP      // timing experiment only (wrong results): no v_exp_f32
+#define SV_EXP2(x_) (x_)
+#else
+#define SV_EXP2(x_) __builtin_amdgcn_exp2f(x_)
+#endif
+#define SV_B_PIN(i_)                                                                                          \
+    if ((i_) == 0) asm volatile("" : "+v"(pa[0]));                                                            \
+    else if ((i_) == 1) asm volatile("" : "+v"(pa[1]), "+v"(c1[0]), "+v"(c1[1]));                             \
+    else if ((i_) <= 8) asm volatile("" : "+v"(pa[(i_) & 1]), "+v"(c1[2 * (i_) - 2]), "+v"(c1[2 * (i_) - 1])  \
+                                          : "v"(pw[(i_) >= 2 ? (i_) - 2 : 0]));                               \
+    else asm volatile("" : "+v"(pa[(i_) & 1]) : "v"(pw[7]));
+#define SV_SL(sub_, i_) ((KS1 * (sub_) + (i_)) % W)       /* window slot, as in phase A */
+#define SV_B_GAP(sub_, i_)                                                                                    \
+    {                                                                                                         \
+        SV_B_PIN(i_)                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fb[SV_SL(sub_, i_)]));                                     \
+        Z[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[(i_) & 1], fb[SV_SL(sub_, i_)], Z[(i_) >> 1], 0, 0, 0); \
+        if ((i_) + W < KS1) fb[SV_SL(sub_, i_)] = SV_YB(tst, sub_, ((i_) + W) % KS1);                         \
+        else if ((sub_) == 0) fb[SV_SL(sub_, i_)] = SV_YB(tst, 1, ((i_) + W) % KS1);                          \
+        else fb[SV_SL(sub_, i_)] = SV_YB(tsn, 0, ((i_) + W) % KS1);                                           \
+        if ((i_) >= 1 && (i_) <= 8) {                                                                         \
+            const float l0_ = c1[2 * (i_) - 2], l1_ = c1[2 * (i_) - 1];                                       \
+            pw[(i_) - 1] = pack_bf16(SV_EXP2(l0_), SV_EXP2(l1_));                                             \
+            /* one v_max3_f32 (fmaxf() also quiets NaNs: two more instructions per logit) */                  \
+            if (MODE != MODE_DW) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm) : "v"(l0_), "v"(l1_));           \
+        }                                                                                                     \
+    }
+                    if (sub == 0) {
+                        SV_B_GAP(0, 0) SV_B_GAP(0, 1) SV_B_GAP(0, 2) SV_B_GAP(0, 3) SV_B_GAP(0, 4)
+                        SV_B_GAP(0, 5) SV_B_GAP(0, 6) SV_B_GAP(0, 7) SV_B_GAP(0, 8) SV_B_GAP(0, 9)
+                    } else {
+                        SV_B_GAP(1, 0) SV_B_GAP(1, 1) SV_B_GAP(1, 2) SV_B_GAP(1, 3) SV_B_GAP(1, 4)
+                        SV_B_GAP(1, 5) SV_B_GAP(1, 6) SV_B_GAP(1, 7) SV_B_GAP(1, 8) SV_B_GAP(1, 9)
                     }
+#undef SV_B_GAP
+#undef SV_B_PIN
+#undef SV_SL
                     if (MODE != MODE_DW && has_next && __any(tm > thr)) {
                         stabilise(c1);
 #pragma unroll
@@ -391,13 +512,8 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                     pa[1] = __builtin_bit_cast(bf16x8, (uint4){pw[4], pw[5], pw[6], pw[7]});
                 }
             }
-            // the one barrier of the tile (see above)
-            if (!dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NIMG) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIMG) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            SV_TILE_BARRIER
+            sj = sn;
         }
 #ifdef SV_PROJ_TIMING
         if (lane == 0 && wave == 0 && blockIdx.x < 4096) {
@@ -410,7 +526,13 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
 #undef SV_DMA
 #undef SV_YA
 #undef SV_YB
+#undef SV_TR
 #undef SV_MFMA_DS
+#undef SV_PIECE1
+#undef SV_WAIT_TILES
+#undef SV_TILE_BARRIER
+#undef SV_BARRIER_INSN
+#undef SV_LGKM0_INSN
     }
     } else if constexpr (!SPLIT) {
     // Three LDS stages; tile t lives in stage (t - t_begin) % 3.  An LDS-DMA piece takes 1-2 us from issue to

@@ -356,6 +356,16 @@ class SVAEEngine:
         self._ensure(R)
         w, st = self.ws, _stream()
         self._plan, self._anneal = plan, float(anneal)
+        if getattr(plan, "ready", None) is not None:      # uploaded on a copy stream (batch.PlanPrefetcher)
+            cur.wait_event(plan.ready)
+            plan.ready = None
+            # its buffers were allocated on that stream: tell the allocator which streams read them, or a later
+            # upload could reuse the memory while this step's kernels are still running
+            streams = [cur] + list(self._sides)
+            for t in [plan._buf] + [v[0] for v in plan.proj_sched.values()]:
+                if t is not None and t.is_cuda:
+                    for s_ in streams:
+                        t.record_stream(s_)
         params_ready = None
         eps_done = False
         if self.fused and self.overlap:

@@ -431,7 +431,7 @@ def users_anneal(users_before, total_anneal_steps=200000, cap=0.2):
 
 
 def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, log=None, grad_sync=None,
-                  rank=0, world=1, anneal_by="users"):
+                  rank=0, world=1, anneal_by="users", workers=6):
     """One epoch with B users per step (length-bucketed, user-sharded over ranks).
 
     KL anneal: the reference's schedule advances once per user (one user = one optimizer step there).  With
@@ -452,10 +452,12 @@ def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, 
     eng.grad_sync = grad_sync
     k = reader._k()
     users_before = 0
-    for b, idx in enumerate(batches, start=1):
-        plan = build_plan([np.asarray(reader.data[i]) for i in idx], k, user_keys=idx, device=eng.device,
-                          total_items=eng.I)
-        eng.prepare(plan)
+    # plans (the per-user work of DataReader.iter, nb:485-526) are built and uploaded ahead of the GPU by worker
+    # threads; the step only waits for an event
+    from .batch import PlanPrefetcher
+    plans = PlanPrefetcher(batches, reader.data, k, eng.device, total_items=eng.I, prepare=eng.prepare,
+                           workers=workers, depth=2 * workers)
+    for b, (idx, plan) in enumerate(zip(batches, plans), start=1):
         anneal = users_anneal(users_before) if anneal_by == "users" else anneal_for_batch(b)
         eng.train_step(plan, anneal, seed=seed + epoch)
         users_before += len(idx) * world
