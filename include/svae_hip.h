@@ -273,6 +273,31 @@ int svae_masked_topk(const float* scores, int ld, const int* seen, const int* se
 int svae_masked_topk_static(const float* scores, int ld, const int* seen, const int* seen_off, int n_users, int I,
                             int K, int* out_idx, float* out_val, void* stream);
 
+/* ---- batch plans (HOST functions, no GPU work) -------------------------------------------------------------
+ * Replaces the per-user packing of DataReader.iter (nb:485-526: x [1,T] and the dense one-hot next-k targets
+ * y_s [1,T,I] of nb:509-513) for a BATCH of users: time-major rows, users sorted by length, int32 target table with
+ * duplicates inside a row removed (scatter_ semantics), per-row loss weights (nb:797, nb:803, nb:808), rows grouped by
+ * input item, target occurrences grouped by item.  The dataset is CSR: items[user_off[u] .. user_off[u+1]) are user
+ * u's item ids in time order (at least 2).  idx[B] = the batch's users, keys[B] = their ids for the counter-based
+ * noise (NULL: position in the batch).  next_k as hyper_params['next_k'] (nb:88).  total_items = 0 leaves the
+ * occurrence tables out.  Thread-safe (no shared state); meant to be called from worker threads.
+ *   svae_plan_create   builds the plan in host memory and fills `info`; NULL on error (svae_last_error)
+ *   svae_plan_pack     copies it as ONE packed buffer (every array at a multiple of 256 bytes, info.off[i] = byte
+ *                      offset of array i in the order x, tgt [R][K], w_nll, w_kl, row_off [Tmax+1], nact [Tmax],
+ *                      last_row [B], perm [R], seg_off [nseg+1], seg_item [nseg], row_key [R] (int64), seen [R],
+ *                      seen_off [B+1], occ_off [I+1], occ_row [nocc], occ_items [I]) into dst -- e.g. pinned memory,
+ *                      uploaded with one copy -- and the host-side tables order [B], lengths [B] (int64), row_off
+ *   svae_plan_destroy  frees it */
+typedef struct svae_plan_info {
+    int B, R, Tmax, K, nseg, nseg_long, nocc, nocc_long, split_t, split_r, total_items, reserved;
+    long long total_bytes;
+    long long off[16];
+} svae_plan_info;
+void* svae_plan_create(const int* items, const long long* user_off, const long long* idx, const long long* keys,
+                       int B, int next_k, int total_items, svae_plan_info* info);
+int svae_plan_pack(void* plan, void* dst, long long dst_bytes, long long* order, long long* lengths, int* row_off);
+void svae_plan_destroy(void* plan);
+
 /* ---- helpers -------------------------------------------------------------------------------------------- */
 int svae_colsum(const float* a, float* out, float* partials, int R, int N, int ld, int nparts, void* stream);
 int svae_transpose(const float* in, float* out, int rows, int cols, void* stream);

@@ -141,6 +141,34 @@ def proj_schedule(nx, ny, ncu, uniform=False):
     return buf[:n].copy(), q.value, rem.value
 
 
+
+class PlanInfo(_c.Structure):
+    """struct svae_plan_info (include/svae_hip.h)."""
+    _fields_ = [(n, _I) for n in ("B", "R", "Tmax", "K", "nseg", "nseg_long", "nocc", "nocc_long", "split_t", "split_r",
+                                  "total_items", "reserved")] + [("total_bytes", _LL), ("off", _LL * 16)]
+
+
+_plan_fns = None
+
+
+def plan_fns():
+    """(create, pack, destroy) of the host-side plan builder, argtypes set; ctypes drops the interpreter lock for the
+    duration of each call, so worker threads build plans side by side."""
+    global _plan_fns
+    if _plan_fns is None:
+        lib = load()
+        cr, pk, ds = lib.svae_plan_create, lib.svae_plan_pack, lib.svae_plan_destroy
+        cr.argtypes, cr.restype = [_P, _P, _P, _P, _I, _I, _I, _c.POINTER(PlanInfo)], _c.c_void_p
+        pk.argtypes, pk.restype = [_c.c_void_p, _P, _LL, _P, _P, _P], _I
+        ds.argtypes, ds.restype = [_c.c_void_p], None
+        _plan_fns = (cr, pk, ds)
+    return _plan_fns
+
+
+def last_error():
+    return load().svae_last_error().decode("utf-8", "replace")
+
+
 class DispatchTimer:
     """A start / stop event pair attached to ONE kernel dispatch (svae_proj_time_next); quacks like the
     (start, stop) pairs of torch events the engine's profiling lists hold: ``pair[0].elapsed_time(pair[1])``."""

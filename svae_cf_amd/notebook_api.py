@@ -431,7 +431,7 @@ def users_anneal(users_before, total_anneal_steps=200000, cap=0.2):
 
 
 def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, log=None, grad_sync=None,
-                  rank=0, world=1, anneal_by="users", workers=6):
+                  rank=0, world=1, anneal_by="users", workers=2):
     """One epoch with B users per step (length-bucketed, user-sharded over ranks).
 
     KL anneal: the reference's schedule advances once per user (one user = one optimizer step there).  With
@@ -447,22 +447,30 @@ def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, 
         raise ValueError("anneal_by must be 'users' or 'steps'")
     eng = model.engine
     rng = np.random.default_rng(seed + 1000 * epoch)
-    lens = [len(u) for u in reader.data]
-    batches = rank_batches(lens, batch_size, rng, rank, world)
     eng.grad_sync = grad_sync
     k = reader._k()
     users_before = 0
     # plans (the per-user work of DataReader.iter, nb:485-526) are built and uploaded ahead of the GPU by worker
-    # threads; the step only waits for an event
-    from .batch import PlanPrefetcher
-    plans = PlanPrefetcher(batches, reader.data, k, eng.device, total_items=eng.I, prepare=eng.prepare,
-                           workers=workers, depth=2 * workers)
+    # threads (the library's host-side builder, over ONE flat copy of the reader's per-user lists made on the first
+    # epoch); the step only waits for an event
+    from .batch import PlanPrefetcher, UserCSR
+    csr = getattr(reader, "_svae_csr", None)
+    if csr is None or csr[0] is not reader.data or len(csr[1]) != len(reader.data):
+        csr = (reader.data, UserCSR(reader.data))
+        try:
+            reader._svae_csr = csr
+        except AttributeError:
+            pass
+    batches = rank_batches(np.diff(csr[1].off), batch_size, rng, rank, world)
+    plans = PlanPrefetcher(batches, csr[1], k, eng.device, total_items=eng.I, prepare=eng.prepare,
+                           workers=workers, depth=4 * workers)
     for b, (idx, plan) in enumerate(zip(batches, plans), start=1):
         anneal = users_anneal(users_before) if anneal_by == "users" else anneal_for_batch(b)
         eng.train_step(plan, anneal, seed=seed + epoch)
         users_before += len(idx) * world
         if log is not None and b % max(1, hyper_params["batch_log_interval"] // batch_size) == 0:
             log("| epoch {:3d} | {:5d}/{:5d} batches | loss {:5.4f}".format(epoch, b, len(batches), float(eng.loss_out[0])))
+    train_batched.last_wait_s = plans.wait_s          # (diagnostic: time the loop spent waiting for plans)
     return len(batches)
 
 

@@ -374,3 +374,46 @@ def test_reference_init_draws_from_global_generator():
     assert not torch.equal(a["item_embed.weight"], c["item_embed.weight"])
     s1, s2 = N.reference_init(40, hp, seed=5), N.reference_init(40, hp, seed=5)
     assert all(torch.equal(s1[k], s2[k]) for k in s1)
+
+
+@pytest.mark.parametrize("I,nu,mu,sg,lmax,k,occ", [(300, 48, 2.8, 0.6, 60, 4, True), (300, 17, 2.8, 0.6, 60, 1, True),
+                                                  (97, 9, 2.0, 0.5, 40, 10 ** 6, True), (2000, 64, 3.5, 0.8, 300, 4, True),
+                                                  (50, 30, 3.0, 0.5, 80, 4, False), (20, 33, 3.0, 0.5, 300, 10 ** 6, True)])
+def test_native_plan_builder_equals_numpy_builder(I, nu, mu, sg, lmax, k, occ):
+    """svae_plan_create / svae_plan_pack (csrc/plan.hip, host code) against batch.build_plan, byte for byte: every
+    table, the host-side order / lengths / row_of, the time split; next_k 1, 4 and postfix; duplicate targets inside
+    a row; with and without the occurrence tables; with and without user keys."""
+    from svae_cf_amd import synth
+    from svae_cf_amd.batch import build_plan, build_plan_native, UserCSR
+    rng = np.random.default_rng(I + nu)
+    users = [np.asarray(u).copy() for u in synth.make_users(nu, I, mu, sg, lmax, seed=I)]
+    users[0][1:3] = users[0][0]                       # duplicates among the next-k targets
+    csr = UserCSR([u.tolist() for u in users])
+    assert len(csr) == nu and csr.items.dtype == np.int32
+    idx = rng.permutation(nu)[:max(2, nu - 3)]
+    for keys in (idx, None):
+        a = build_plan([users[i] for i in idx], k, user_keys=keys, total_items=I if occ else None)
+        b = build_plan_native(csr, idx, k, user_keys=keys, total_items=I if occ else None)
+        for n in ("B", "R", "Tmax", "K", "nseg", "nseg_long", "nocc_long", "split_t", "split_r"):
+            assert getattr(a, n) == getattr(b, n), n
+        assert np.array_equal(a.order, b.order) and np.array_equal(a.lengths, b.lengths)
+        for n in ("x", "tgt", "w_nll", "w_kl", "row_off", "nact", "last_row", "perm", "seg_off", "seg_item", "row_key",
+                  "seen", "seen_off", "occ_off", "occ_row", "occ_items"):
+            x, y = getattr(a, n), getattr(b, n)
+            if x is None or y is None:
+                assert x is None and y is None, n
+                continue
+            assert x.dtype == y.dtype and x.shape == y.shape, n
+            assert np.array_equal(x.numpy().view(np.uint8), y.numpy().view(np.uint8)), n
+        for u in range(a.B):
+            assert np.array_equal(a.row_of[u], b.row_of[u])
+
+
+def test_native_plan_builder_errors():
+    from svae_cf_amd.batch import build_plan_native, UserCSR
+    with pytest.raises(ValueError):
+        build_plan_native(UserCSR([[1], [1, 2]]), [0, 1], 4)          # a user with one item (nb:803 divides by zero)
+    with pytest.raises(IndexError):
+        build_plan_native(UserCSR([[1, 2], [1, 2]]), [0, 2], 4)
+    with pytest.raises(Exception):
+        build_plan_native(UserCSR([[1, 2, 7], [1, 2]]), [0, 1], 4, total_items=5)   # item id beyond the catalogue

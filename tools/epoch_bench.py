@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end epoch throughput through the product's own entry point (notebook_api.train_batched: plans built from
 the reader's per-user lists by the prefetcher's worker threads, uploaded, trained on) beside the kernel-pipeline
-figure of bench.py (plans pre-built and resident).  ML-20M shape, 64 batches of 256 users.
+figure of bench.py (plans pre-built and resident).  ML-20M shape, 256 batches of 256 users.
 
     python tools/epoch_bench.py [workers]
 """
@@ -14,7 +14,7 @@ from svae_cf_amd.batch import build_plan
 
 workers = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 _, I, mu, sigma, lmax = synth.SHAPES["ml-20m"]
-B, NB = 256, 64
+B, NB = 256, int(os.environ.get('SVAE_EPOCH_BATCHES', '256'))
 users = synth.make_users(B * NB, I, mu, sigma, lmax, seed=98765)
 
 
@@ -35,6 +35,7 @@ for tag, w in (("warmup", workers), ("epoch", workers)):
     n = N.train_batched(reader, model, hp, batch_size=B, epoch=1, seed=0, workers=w)
     torch.cuda.synchronize()
     out[tag] = time.perf_counter() - t0
+    out[tag + "_wait"] = N.train_batched.last_wait_s
 # the kernel pipeline alone on the same batches (plans resident), and the plan builder alone (one thread)
 from svae_cf_amd.dist import rank_batches
 batches = rank_batches([len(u) for u in reader.data], B, np.random.default_rng(0 + 1000 * 1), 0, 1)
@@ -42,6 +43,12 @@ t0 = time.perf_counter()
 plans = [build_plan([np.asarray(reader.data[i]) for i in idx], 4, user_keys=idx, device="cuda", total_items=I) for idx in batches]
 torch.cuda.synchronize()
 t_build = time.perf_counter() - t0
+from svae_cf_amd.batch import build_plan_native, UserCSR
+csr = UserCSR(reader.data)
+t0 = time.perf_counter()
+plans = [build_plan_native(csr, idx, 4, user_keys=idx, device="cuda", total_items=I, pin=True) for idx in batches]
+torch.cuda.synchronize()
+t_build_native = time.perf_counter() - t0
 eng = model.engine
 for p in plans:
     eng.prepare(p)
@@ -58,5 +65,6 @@ print(json.dumps({"metric": "end-to-end train sequences/s through train_batched 
                   "batches": n, "workers": workers, "ms_per_step_end_to_end": out["epoch"] / n * 1e3,
                   "resident_plans_seq_per_s": nu / t_res, "ms_per_step_resident": t_res / n * 1e3,
                   "ratio": (nu / out["epoch"]) / (nu / t_res),
+                  "build_plan_native_ms_per_batch_one_thread_incl_upload": t_build_native / n * 1e3,
                   "build_plan_ms_per_batch_one_thread_incl_upload": t_build / n * 1e3,
-                  "first_epoch_s": out["warmup"]}))
+                  "first_epoch_s": out["warmup"], "loop_blocked_on_plans_ms_per_step": out["epoch_wait"] / n * 1e3}))
