@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--items", type=int, default=None, help="catalogue size (default: the shape's)")
     ap.add_argument("--nplans", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-leg", action="store_true", help="also time the scoring leg (forward + masked top-100)")
     ap.add_argument("--no-kernel-times", action="store_true", help="do not bracket kernels with events (no roofline)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions in all: the first is the contractual one (`value`), the others give the spread")
@@ -278,6 +279,38 @@ def main():
     elif rooflines:
         roofline = rooflines[max(rooflines, key=lambda k: rooflines[k]["avg_ms"])]
 
+    # Scoring leg (evaluate()'s per-user work, nb:615-636): forward without gradients, the last timestep's logits
+    # dense, seen items masked, top-100.  The ranking kernel reads the [users, I] scores once: HBM-bound.
+    ev_leg = None
+    if rank == 0 and (args.eval_leg or args.shape == "large"):
+        from svae_cf_amd import _lib as L
+        p0 = plans[0]
+        for _ in range(2):
+            eng.score(p0, topk=100, seed=3)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nrep = 5
+        e0.record()
+        for _ in range(nrep):
+            _, idx_k, val_k, last = eng.score(p0, topk=100, seed=3)
+        e1.record()
+        torch.cuda.synchronize()
+        score_ms = e0.elapsed_time(e1) / nrep
+        work = torch.empty(p0.B * eng.IP, device=eng.device, dtype=torch.float32)
+        st = torch.cuda.current_stream().cuda_stream
+        e0.record()
+        for _ in range(nrep):
+            L.call("svae_masked_topk", last.data_ptr(), eng.IP, p0.seen.data_ptr(), p0.seen_off.data_ptr(), p0.B, I, 100,
+                   idx_k.data_ptr(), val_k.data_ptr(), work.data_ptr(), st)
+        e1.record()
+        torch.cuda.synchronize()
+        topk_ms = e0.elapsed_time(e1) / nrep
+        tb = float(p0.B) * I * 4
+        ev_leg = dict(users=p0.B, rows=p0.R, score_ms=score_ms, users_per_s=p0.B / (score_ms * 1e-3),
+                      topk=dict(kernel="svae_masked_topk (k=100)", ms=topk_ms, algorithmic_bytes=tb, bound="hbm",
+                                achieved=tb / (topk_ms * 1e-3) / 1e9, peak=PEAK["hbm"], unit="GB/s",
+                                frac=tb / (topk_ms * 1e-3) / 1e9 / PEAK["hbm"]))
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import svae_torch as TP           # checker / baseline leg only
@@ -305,6 +338,8 @@ def main():
                                              "(events inside the timed region stall the launch pipeline)" % replay_steps, "roofline": roofline, "rooflines": rooflines,
             "cpu_baseline": cpu,
         }
+        if ev_leg is not None:
+            out["eval_leg"] = ev_leg
         print(json.dumps(out))
     if world > 1 or rehearse:
         dist.destroy_process_group()
