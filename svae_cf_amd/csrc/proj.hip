@@ -55,9 +55,12 @@
 #ifdef SV_PROJ_TIMING   // diagnostic build only (tools/proj_timing.py): phase stamps of waves 0 and 4 of block 0
 __device__ unsigned long long g_proj_dbg[3][2][8];
 __device__ unsigned long long g_proj_blk[3][4096][4];   // per block (wave 0): realtime at start, at end, loop cycles, tiles
+__device__ unsigned long long g_proj_wv[3][8][8][8];    // block 0, per wave, tiles 8..15: cycle stamps (see SV_WSTAMP)
+#define SV_WSTAMP(k_) if (blockIdx.x == 0 && j >= 8 && j < 16 && lane == 0) g_proj_wv[MODE][wave][j - 8][k_] = __builtin_amdgcn_s_memtime();
 #define SV_TS(i_) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts_acc[i_] += now_ - ts_last; ts_last = now_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define SV_TS(i_)
+#define SV_WSTAMP(k_)
 #endif
 namespace {
 
@@ -303,16 +306,33 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     //
     // (Tried: a stagger -- waves 4..7 taking the tile's barrier one phase earlier in program order, so that SIMD
     //  partners run A beside B: 3297 -> 3202 cycles per tile in the DW sweep, and 95 spilled registers in the FDH one,
-    //  whose mid-iteration barrier keeps the logits alive across it; a barrier every other tile: 3194.  Not kept.
-    //  Timing builds without v_exp (-160 cycles), without LDS-DMA in the loop (0) and without the LDS drain in front
-    //  of the barrier (0) say the remaining 25 % over the matrix pipe's 2560 cycles per tile is neither of those.)
+    //  whose mid-iteration barrier keeps the logits alive across it; a barrier every other tile: 3194; issue priority
+    //  (s_setprio) alternating between the two waves of a SIMD every half tile: the arrival spread at the barrier
+    //  falls from ~650 to ~250 cycles, the tile takes as long as before.  None kept.)
     constexpr int W = 4;
-    constexpr int NSTP = 6;                       // stages; tiles j+3 .. j+NSTP-1 are in flight behind tile j's barrier
     constexpr int PSTAGE = YIMG_BYTES;
+    constexpr int NSTP = 7;                       // stages; tile j+NSTP-2 is issued during tile j, into tile j-2's stage
+    constexpr int DAH = NSTP - 2;                 // how many tiles ahead the LDS-DMA runs
     const int ntile = t_end - t_begin;
-    const int npc = wave < 4 ? 3 : 2;             // this wave's pieces of a tile (20 pieces of 1 KiB over 8 waves)
+    // This wave's pieces of a tile (20 pieces of 1 KiB over 8 waves): pieces w and w + 8, and waves 4..7 also piece
+    // w + 12.  The odd four pieces go to the YOUNGER wave of each SIMD: with the third piece on waves 0..3 -- the ones
+    // that win the issue arbitration against their SIMD partners -- a loop of nothing but this kernel's 80 MFMAs per
+    // SIMD, its LDS-DMA and the barrier ran 3661 cycles per tile, with it on waves 4..7 2763, with three pieces on
+    // every wave 2682, with none 2560 (tools/probe/mfma_probe.hip).
+    // (In this kernel the move is worth 1 %; a dummy fourth piece on waves 0..3, three on every wave: nothing more.)
+    const int npc = wave >= 4 ? 3 : 2;
+    unsigned offY3;                               // source offset of the third piece: chunk tid + 768
+    {
+        const int p = tid + 768;
+        const int row = p / 20, cs = p % 20;
+        offY3 = (unsigned)(row * (KP * 2) + 16 * (cs ^ ((row >> 2) & 3)));
+    }
     if (ntile > 0) {
-#define SV_PIECE1(q_, ybase_, lbase_) glds16((ybase_) + offY[q_], (lbase_) + 8192 * (q_));
+#define SV_PIECE1(q_, ybase_, lbase_)                                                   \
+    {                                                                                   \
+        if ((q_) < 2) glds16((ybase_) + offY[(q_) & 1], (lbase_) + 8192 * (q_));         \
+        else glds16((ybase_) + offY3, (lbase_) + 12288);                                \
+    }
         // wait until all but the youngest c_ tiles' pieces of this wave have landed (c_ uniform, 0 .. NSTP-3)
 #define SV_WAIT_TILES(c_)                                                                    \
     {                                                                                        \
@@ -325,7 +345,7 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 \
     }
 #pragma unroll
-        for (int j = 0; j < NSTP - 1; ++j)
+        for (int j = 0; j < DAH; ++j)
             if (j < ntile) {
                 const char* yb_ = Yg + (size_t)(t_begin + j) * (BY * KP * 2);
                 char* ly_ = smem + j * PSTAGE + wave * 1024;
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                     if (q_ < npc) SV_PIECE1(q_, yb_, ly_)
             }
         {
-            const int issued = ntile < NSTP - 1 ? ntile : NSTP - 1;
+            const int issued = ntile < DAH ? ntile : DAH;
             SV_WAIT_TILES(issued > 3 ? issued - 3 : 0)          // tiles 0 .. 2 landed
         }
         __syncthreads();
@@ -393,44 +413,41 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
         const unsigned long long blk_rt0 = __builtin_amdgcn_s_memrealtime();
         const unsigned long long blk_c0 = __builtin_amdgcn_s_memtime();
 #endif
-        // the tile's barrier: tile j+2 must have landed; the tiles issued behind it (up to j+NSTP-1) stay in flight
-#define SV_TILE_BARRIER                                                             \
+        // The tile's barrier: tile j+2 must have landed; the tiles issued behind it (up to j+DAH) stay in flight.
+        // (Tried instead of s_barrier: per-stage "tile done" counters in LDS -- a wave adds one when it is through tile
+        //  j and its pieces of tile j+3 have landed, and only waits until all eight are through tile j-1, so that waves
+        //  run up to a tile apart.  Correct, and 6-9 % SLOWER (FDH 0.257 vs 0.241 ms, DW 0.306 vs 0.280): the two waves
+        //  of a SIMD share one matrix pipe whatever their distance, and the poll costs an LDS round trip per tile.
+        //  What the in-kernel stamps say about a tile's ~3350 cycles (matrix pipe alone: 2560): without any vector work
+        //  and any LDS read the loop -- 80 MFMAs per SIMD, the LDS-DMA of the next tiles, the barrier -- still takes
+        //  ~3050; the exp / pack work costs ~90, the fragment reads ~160.  The LDS-DMA stream beside the MFMAs is what
+        //  the remaining fifth goes to.)
+#define SV_TILE_SYNC                                                                \
     {                                                                               \
-        const int last_ = j + NSTP - 1 < ntile ? j + NSTP - 1 : ntile - 1;          \
+        const int last_ = j + DAH < ntile ? j + DAH : ntile - 1;                    \
         SV_WAIT_TILES(last_ > j + 2 ? last_ - (j + 2) : 0)                          \
-        SV_LGKM0_INSN                                                               \
-        SV_BARRIER_INSN                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_s_barrier();                                               \
         asm volatile("" ::: "memory");                                              \
     }
-#if defined(SV_EXP_NOBAR)     // (timing experiments only: no barrier / a barrier every other tile / no LDS drain)
-#define SV_BARRIER_INSN
-#elif defined(SV_EXP_BAR2)
-#define SV_BARRIER_INSN if (j & 1) __builtin_amdgcn_s_barrier();
-#else
-#define SV_BARRIER_INSN __builtin_amdgcn_s_barrier();
-#endif
-#ifdef SV_EXP_NOLGKM
-#define SV_LGKM0_INSN
-#else
-#define SV_LGKM0_INSN asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
         int sj = 0;                                       // stage of tile j
         for (int j = 0; j < ntile; ++j) {
             const int sn = sj + 1 == NSTP ? 0 : sj + 1;   // stage of tile j+1
-            const int sd = sj == 0 ? NSTP - 1 : sj - 1;   // stage of tile j-1 = stage of tile j+NSTP-1
+            const int sd = sj + DAH >= NSTP ? sj + DAH - NSTP : sj + DAH;   // stage of tile j+DAH (= of tile j-2)
             const char* st = smem + sj * PSTAGE;
             const char* stn = smem + sn * PSTAGE;
             const unsigned tst[2] = {lds0 + (unsigned)(sj * PSTAGE + tb[0]), lds0 + (unsigned)(sj * PSTAGE + tb[1])};
             const unsigned tsn[2] = {lds0 + (unsigned)(sn * PSTAGE + tb[0]), lds0 + (unsigned)(sn * PSTAGE + tb[1])};
             const bool more = j + 1 < ntile;              // a next tile exists
-            const bool dma = j + NSTP - 1 < ntile;        // tile j+NSTP-1 is issued during this tile's iterations
-            const char* dy = Yg + (size_t)(t_begin + j + NSTP - 1) * (BY * KP * 2);
+            const bool dma = j + DAH < ntile;             // tile j+DAH is issued during this tile's iterations
+            const char* dy = Yg + (size_t)(t_begin + j + DAH) * (BY * KP * 2);
             char* dl = smem + sd * PSTAGE + wave * 1024;
 #ifdef SV_EXP_NODMA      // timing experiment only (wrong results): no LDS-DMA inside the loop
 #define SV_DMA(q_) {}
 #else
 #define SV_DMA(q_) if (dma && (q_) < npc) SV_PIECE1(q_, dy, dl)
 #endif
+            SV_WSTAMP(0)
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const bool has_next = sub == 0 || more;   // sub-tile k+1 exists
@@ -445,12 +462,15 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                         //  two phases, and W divides 2 KS1, not KS1)
                         const int sl = (KS1 * sub + s) % W;
                         c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sl], xf[s], c1, 0, 0, 0);
+#ifndef SV_EXP_NOFA
                         fa[sl] = s + W < KS1 ? SV_YA(a1, 1 - sub, s + W) : SV_YA(stn, sub, s + W - KS1);
+#endif
                         SV_MFMA_DS
                         if (s == 2) SV_DMA(sub)
                         if (sub == 0 && s == 6) SV_DMA(2)
                     }
                 }
+                SV_WSTAMP(1 + 2 * sub)
                 // ---- B: GEMM2(k) beside the vector work of sub-tile k+1; the Y^T window moves on
                 // Gap i = MFMA i, one transposed fragment (two reads), and for i = 1..8 two v_exp + one v_cvt_pk of
                 // sub-tile k+1 (gap 0 stays bare: the logits come out of GEMM1's last MFMA, still in flight) and one
@@ -477,15 +497,26 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                                           : "v"(pw[(i_) >= 2 ? (i_) - 2 : 0]));                               \
     else asm volatile("" : "+v"(pa[(i_) & 1]) : "v"(pw[7]));
 #define SV_SL(sub_, i_) ((KS1 * (sub_) + (i_)) % W)       /* window slot, as in phase A */
+#ifdef SV_EXP_NOVALU     /* timing builds only (wrong results): no vector work / no transposed reads in the gaps */
+#define SV_GAP_VALU 0
+#else
+#define SV_GAP_VALU 1
+#endif
+#ifdef SV_EXP_NOTR
+#define SV_GAP_TR 0
+#else
+#define SV_GAP_TR 1
+#endif
 #define SV_B_GAP(sub_, i_)                                                                                    \
     {                                                                                                         \
         SV_B_PIN(i_)                                                                                          \
         asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fb[SV_SL(sub_, i_)]));                                     \
         Z[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[(i_) & 1], fb[SV_SL(sub_, i_)], Z[(i_) >> 1], 0, 0, 0); \
-        if ((i_) + W < KS1) fb[SV_SL(sub_, i_)] = SV_YB(tst, sub_, ((i_) + W) % KS1);                         \
+        if (!SV_GAP_TR) {}                                                                                    \
+        else if ((i_) + W < KS1) fb[SV_SL(sub_, i_)] = SV_YB(tst, sub_, ((i_) + W) % KS1);                    \
         else if ((sub_) == 0) fb[SV_SL(sub_, i_)] = SV_YB(tst, 1, ((i_) + W) % KS1);                          \
         else fb[SV_SL(sub_, i_)] = SV_YB(tsn, 0, ((i_) + W) % KS1);                                           \
-        if ((i_) >= 1 && (i_) <= 8) {                                                                         \
+        if (SV_GAP_VALU && (i_) >= 1 && (i_) <= 8) {                                                          \
             const float l0_ = c1[2 * (i_) - 2], l1_ = c1[2 * (i_) - 1];                                       \
             pw[(i_) - 1] = pack_bf16(SV_EXP2(l0_), SV_EXP2(l1_));                                             \
             /* one v_max3_f32 (fmaxf() also quiets NaNs: two more instructions per logit) */                  \
@@ -511,8 +542,10 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                     pa[0] = __builtin_bit_cast(bf16x8, (uint4){pw[0], pw[1], pw[2], pw[3]});
                     pa[1] = __builtin_bit_cast(bf16x8, (uint4){pw[4], pw[5], pw[6], pw[7]});
                 }
+                SV_WSTAMP(2 + 2 * sub)
             }
-            SV_TILE_BARRIER
+            SV_TILE_SYNC
+            SV_WSTAMP(7)
             sj = sn;
         }
 #ifdef SV_PROJ_TIMING
@@ -530,9 +563,7 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
 #undef SV_MFMA_DS
 #undef SV_PIECE1
 #undef SV_WAIT_TILES
-#undef SV_TILE_BARRIER
-#undef SV_BARRIER_INSN
-#undef SV_LGKM0_INSN
+#undef SV_TILE_SYNC
     }
     } else if constexpr (!SPLIT) {
     // Three LDS stages; tile t lives in stage (t - t_begin) % 3.  An LDS-DMA piece takes 1-2 us from issue to
@@ -1151,6 +1182,9 @@ int launch_proj(ProjArgs a, int nwg, hipStream_t st) {
 #ifdef SV_PROJ_TIMING
 extern "C" int svae_debug_proj(unsigned long long* out48) {
     return (int)hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_proj_dbg), 48 * sizeof(unsigned long long));
+}
+extern "C" int svae_debug_proj_waves(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_proj_wv), sizeof(unsigned long long) * 3 * 8 * 8 * 8);
 }
 extern "C" int svae_debug_proj_blocks(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_proj_blk), 3 * 4096 * 4 * sizeof(unsigned long long));

@@ -8,7 +8,10 @@ import sys
 
 bench = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 rows = list(csv.DictReader(open(sys.argv[2])))
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else bench["warmup"] + 2 * bench["steps"]
+# steps in the trace: warm-up + the timed region repeated ms_per_step_regions.n times + the replay pass of the kernel
+# brackets; counted from the trace itself (one optimizer launch set per step) when it holds the adam kernel
+regions = bench.get("ms_per_step_regions", {}).get("n", 1)
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else bench["warmup"] + (regions + 1) * bench["steps"]
 tot = {}
 for r in rows:
     tot[r["Name"]] = tot.get(r["Name"], 0.0) + float(r["TotalDurationNs"])
@@ -18,10 +21,15 @@ def trace_ms(*subs):
     return sum(v for k, v in tot.items() if any(s in k for s in subs)) / steps * 1e-6
 
 
-pairs = [("proj_fdh_fused", ("proj_kernel<1>",)), ("proj_dw_fused", ("proj_kernel<2>",)),
+pairs = [("proj_fdh_fused", ("proj_kernel<1>", "proj_kernel<1,")), ("proj_dw_fused", ("proj_kernel<2>", "proj_kernel<2,")),
          ("gru_fwd", ("gru_fwd_bf16_kernel",)), ("gru_bwd", ("gru_bwd_bf16_kernel",)),
          ("wgrad", ("wgrad_kernel",)), ("gi_gemm", ("rowgemm_kernel<0",)), ("demb_gemm", ("rowgemm_kernel<1",)),
          ("mlp_fwd", ("mlp_fwd_kernel",)), ("mlp_bwd", ("mlp_bwd_kernel",))]
+calls = {}
+for r in rows:
+    calls[r["Name"]] = calls.get(r["Name"], 0) + int(float(r["Calls"]))
+fdh_calls = sum(v for k, v in calls.items() if "proj_kernel<1" in k)
+print("launches of the forward + dL/dh sweep in the trace: %d (steps assumed: %d)\n" % (fdh_calls, steps))
 print("| kernel (bench tag) | bench.py kernel_ms (per step) | rocprofv3 trace (per step) | ratio |")
 print("|---|---|---|---|")
 for tag, subs in pairs:

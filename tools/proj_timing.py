@@ -49,3 +49,21 @@ for mode, name in ((1, "FDH"), (2, "DW")):
           " end deciles:", np.round(np.percentile(end, [0, 10, 25, 50, 75, 90, 100]), 1))
     clk = m[:, 2] / np.maximum((m[:, 1] - m[:, 0]) * 10.0, 1)          # cycles per ns
     print("   in-kernel clock GHz: median %.2f" % np.median(clk))
+
+wv = (ctypes.c_ulonglong * (3 * 8 * 8 * 8))()
+lib.svae_debug_proj_waves.argtypes = [ctypes.c_void_p]
+lib.svae_debug_proj_waves(ctypes.byref(wv))
+w = np.array(list(wv), dtype=np.float64).reshape(3, 8, 8, 8)
+for mode, name in ((1, "FDH"), (2, "DW")):
+    m = w[mode]
+    if m.max() == 0:
+        continue
+    t0 = m[:, 0, 0].min()
+    print("%s block 0, tiles 8..15, per wave: [A0, B0, A1, B1, end-of-tile sync] cycles (median over tiles); arrival skew at the barrier" % name)
+    m = m[:, :, [0, 1, 2, 3, 4, 7]]              # (stamps 5, 6 belonged to the s_barrier form)
+    ph = np.diff(m, axis=2)                      # [wave][tile][5]
+    for wv_ in range(8):
+        print("   wave %d: %s   tile total %.0f" % (wv_, np.round(np.median(ph[wv_], axis=0), 0), np.median(m[wv_, 1:, 0] - m[wv_, :-1, 0])))
+    arr = m[:, :, 4]                             # arrival at the barrier [wave][tile]
+    print("   barrier arrival spread per tile (max - min over waves):", np.round(arr.max(axis=0) - arr.min(axis=0), 0))
+    print("   arrival order example (tile 10, cycles after first):", np.round(arr[:, 2] - arr[:, 2].min(), 0))
