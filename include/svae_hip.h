@@ -154,6 +154,8 @@ int svae_loss_reduce(const float* nll_row, const float* kl_row, const float* w_n
  *                         batch); slabs = 16 I 160 floats; occ_off [I+1] / occ_row = target occurrences by item,
  *                         occ_items [I] = items by occurrence count (descending), the first nocc_long of them
  *                         with more than svae_proj_occ_long() occurrences
+ * The transposed copies h2tb / w3tb are read by the split instantiation (prec 2) only -- the bf16 sweeps take Y^T out
+ * of the row-major image with transposed LDS reads -- and may be NULL everywhere when the part strides are 0.
  * R_pad, I_pad: multiples of 64.  parts (bit mask, 3 = everything): 1 sweep kernel, 2 finish kernel -- the
  * split exists so a profiler can bracket one kernel.
  * Work division: every sweep takes a schedule built ONCE per shape by svae_proj_schedule (a HOST function:

@@ -317,8 +317,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
                 us.x = hs[0] | ((unsigned)hs[1] << 16); us.y = hs[2] | ((unsigned)hs[3] << 16);
                 *reinterpret_cast<uint2*>(a.h2b + (size_t)r * SV_DP + c0) = up;
                 *reinterpret_cast<uint2*>(a.h2s + (size_t)r * SV_DP + c0) = us;
+                if (a.h2tb != nullptr) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a.h2tb[(size_t)(c0 + i) * a.ldt + kr] = hp[i];
+                    for (int i = 0; i < 4; ++i) a.h2tb[(size_t)(c0 + i) * a.ldt + kr] = hp[i];
+                }
             }
         }
     }
@@ -489,7 +491,8 @@ extern "C" int svae_mlp_fwd_prec(const float* hs, const float* eps, const void* 
 extern "C" int svae_mlp_fwd_prep(const float* hs, const float* eps, const void* frags, const float* b1, const float* bl,
                                  const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R,
                                  int R_pad, int row0, int row1, void* h2b, void* h2s, void* h2tb, void* stream) {
-    SV_CHECK_ARG(hs && eps && frags && b1 && bl && b2 && enc && tmp && z && d1 && kl_row && h2b && h2s && h2tb,
+    // (h2tb may be NULL: the bf16 sweeps read the transpose out of the row-major image)
+    SV_CHECK_ARG(hs && eps && frags && b1 && bl && b2 && enc && tmp && z && d1 && kl_row && h2b && h2s,
                  "svae_mlp_fwd_prep: null pointer");
     SV_CHECK_ARG(R > 0 && R_pad >= R && (R_pad % 64) == 0 && row0 >= 0 && row0 < row1 && row1 <= R_pad && (row0 % 32) == 0 &&
                  row0 < R, "svae_mlp_fwd_prep: bad range [%d, %d) of %d (%d)", row0, row1, R, R_pad);

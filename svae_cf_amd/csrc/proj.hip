@@ -903,6 +903,7 @@ __global__ void proj_prep_kernel(const float* __restrict__ src, const float* __r
             }
         }
     }
+    if (dstT == nullptr) return;          // (uniform) bf16 instantiation: the sweeps transpose on the LDS read
     __syncthreads();
     for (int i = threadIdx.x; i < 32 * KP; i += blockDim.x) {
         const int c = i / 32, r = i % 32;
@@ -1306,7 +1307,8 @@ extern "C" int svae_proj_prep_rows_range(const float* h2, int R, int R_pad, int 
 // 2 part_stride ELEMENTS behind each copy (part_stride >= R_pad * 160; 0: bf16 copies only).
 extern "C" int svae_proj_prep_rows_range_split(const float* h2, int R, int R_pad, int row0, int row1, void* h2b, void* h2s,
                                                void* h2tb, long long part_stride, void* stream) {
-    SV_CHECK_ARG(h2 && h2b && h2s && h2tb && R > 0 && R_pad >= R && (R_pad % BY) == 0, "svae_proj_prep_rows: bad arguments");
+    SV_CHECK_ARG(h2 && h2b && h2s && (h2tb || part_stride == 0) && R > 0 && R_pad >= R && (R_pad % BY) == 0,
+                 "svae_proj_prep_rows: bad arguments");
     SV_CHECK_ARG(part_stride == 0 || (part_stride >= (long long)R_pad * KP && (part_stride % 8) == 0),
                  "svae_proj_prep_rows: bad part stride %lld", part_stride);
     SV_CHECK_ARG(row0 >= 0 && row0 < row1 && row1 <= R_pad && (row0 % 32) == 0 && (row1 % 32) == 0,
@@ -1322,7 +1324,8 @@ extern "C" int svae_proj_prep_rows_range_split(const float* h2, int R, int R_pad
 // w3tb [160][I_pad]; I_pad % 64 == 0.  _split: part_stride as above (>= I_pad * 160).
 extern "C" int svae_proj_prep_items_split(const float* w3, const float* b3, int I, int I_pad, void* w3b, void* w3s,
                                           void* w3tb, long long part_stride, void* stream) {
-    SV_CHECK_ARG(w3 && b3 && w3b && w3s && w3tb && I > 0 && I_pad >= I && (I_pad % BY) == 0, "svae_proj_prep_items: bad arguments");
+    SV_CHECK_ARG(w3 && b3 && w3b && w3s && (w3tb || part_stride == 0) && I > 0 && I_pad >= I && (I_pad % BY) == 0,
+                 "svae_proj_prep_items: bad arguments");
     SV_CHECK_ARG(part_stride == 0 || (part_stride >= (long long)I_pad * KP && (part_stride % 8) == 0),
                  "svae_proj_prep_items: bad part stride %lld", part_stride);
     hipLaunchKernelGGL(proj_prep_kernel<0>, dim3(I_pad / 32), dim3(256), 0, (hipStream_t)stream, w3, b3,
@@ -1387,8 +1390,9 @@ extern "C" int svae_proj_nll_fwd_dh_split(const void* h2s, void* h2b, const void
                                           float* nll_row, float* lse, float* dd1, const int* sched, int nwg, int ns_q,
                                           int ns_rem, int parts, long long row_part_stride, long long item_part_stride,
                                           void* stream) {
-    SV_CHECK_ARG(h2s && h2b && w3b && w3tb && h2 && w3 && b3 && tgt && w_nll && slabs && mpart && nll_row && lse && dd1,
-                 "svae_proj_nll_fwd_dh: null pointer");
+    // (w3tb is read by the split instantiation only: the bf16 sweep transposes on the LDS read; it may be NULL there)
+    SV_CHECK_ARG(h2s && h2b && w3b && (w3tb || row_part_stride == 0) && h2 && w3 && b3 && tgt && w_nll && slabs && mpart &&
+                 nll_row && lse && dd1, "svae_proj_nll_fwd_dh: null pointer");
     SV_CHECK_ARG(R > 0 && I > 0 && K >= 1 && I_pad >= I && (I_pad % BY) == 0 && parts > 0 && parts < 4,
                  "svae_proj_nll_fwd_dh: bad shape");
     const bool split = row_part_stride > 0;
@@ -1429,8 +1433,9 @@ extern "C" int svae_proj_nll_bwd_dw_split(const void* w3s, const void* h2b, cons
                                           float* gw3, float* gb3, const int* sched, int nwg, int ns_q, int ns_rem,
                                           int parts, long long row_part_stride, long long item_part_stride,
                                           void* stream) {
-    SV_CHECK_ARG(w3s && h2b && h2tb && h2 && w_nll && occ_off && occ_row && occ_items && slabs && gw3 && gb3,
-                 "svae_proj_nll_bwd_dw: null pointer");
+    // (h2tb: as w3tb above)
+    SV_CHECK_ARG(w3s && h2b && (h2tb || row_part_stride == 0) && h2 && w_nll && occ_off && occ_row && occ_items && slabs &&
+                 gw3 && gb3, "svae_proj_nll_bwd_dw: null pointer");
     SV_CHECK_ARG(nocc_long >= 0 && nocc_long <= I, "svae_proj_nll_bwd_dw: bad nocc_long");
     SV_CHECK_ARG(R > 0 && I > 0 && I_rows >= I && R_pad >= R && (R_pad % BY) == 0 && parts > 0 && parts < 4,
                  "svae_proj_nll_bwd_dw: bad shape");

@@ -211,7 +211,8 @@ class SVAEEngine:
             m = 3 if self.split else 1
             self.ws["h2b"] = torch.zeros(m * capp * DP, **bf)
             self.ws["h2s"] = torch.zeros(m * capp * DP, **bf)
-            self.ws["h2tb"] = torch.zeros(m * DP * capp, **bf)
+            # (transposed images: read by the split instantiation only; the bf16 sweeps transpose on the LDS read)
+            self.ws["h2tb"] = torch.zeros(m * DP * capp, **bf) if self.split else None
             nsm = _lib.load().svae_proj_ns_max()
             self.ws["part"] = torch.zeros(nsm * capp * 2, **f32)
             self.ws["mpart"] = torch.zeros(nsm * capp, **f32)
@@ -222,7 +223,7 @@ class SVAEEngine:
                 self.mlp_frags = torch.zeros(m * _lib.load().svae_mlp_frag_elems(), **bf)
                 self.w3b = torch.zeros(m * self.IPAD * DP, **bf)
                 self.w3s = torch.zeros(m * self.IPAD * DP, **bf)
-                self.w3tb = torch.zeros(m * DP * self.IPAD, **bf)
+                self.w3tb = torch.zeros(m * DP * self.IPAD, **bf) if self.split else None
 
     def _ps(self, which):
         """Part stride (elements) of the bf16 operand images: 'rows' (h2b / h2s / h2tb) or 'items' (w3b / w3s / w3tb);
@@ -476,7 +477,7 @@ class SVAEEngine:
             self._proj_prepare(R)
             if want_grad:
                 # forward + hidden-side backward in one sweep over the items (dd1 is ready after this)
-                args = (w["h2s"].data_ptr(), w["h2b"].data_ptr(), self.w3b.data_ptr(), self.w3tb.data_ptr(),
+                args = (w["h2s"].data_ptr(), w["h2b"].data_ptr(), self.w3b.data_ptr(), _lib.ptr(self.w3tb),
                         self.IPAD, w["d1"].data_ptr(), self.P("decoder.linear2.weight").data_ptr(),
                         self.P("decoder.linear2.bias").data_ptr(), plan.tgt.data_ptr(), plan.w_nll.data_ptr(),
                         R, self.I, plan.K, w["pslabs"].data_ptr(), w["mpart"].data_ptr(), w["nll_row"].data_ptr(),
@@ -536,15 +537,15 @@ class SVAEEngine:
                       self.P("encoder.linear1.bias").data_ptr(), self.P("linear1.bias").data_ptr(),
                       self.P("decoder.linear1.bias").data_ptr(), w["enc"].data_ptr(), w["tmp"].data_ptr(),
                       w["z"].data_ptr(), w["d1"].data_ptr(), w["kl_row"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
-                      w["h2b"].data_ptr(), w["h2s"].data_ptr(), w["h2tb"].data_ptr(), _stream())
+                      w["h2b"].data_ptr(), w["h2s"].data_ptr(), _lib.ptr(w["h2tb"]), _stream())
             self._toc("mlp_fwd", ev)
         else:
             self._mlp_fwd_rows(r0, r1)
             _lib.call("svae_proj_prep_rows_range", w["d1"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
-                      w["h2b"].data_ptr(), w["h2s"].data_ptr(), w["h2tb"].data_ptr(), _stream())
+                      w["h2b"].data_ptr(), w["h2s"].data_ptr(), _lib.ptr(w["h2tb"]), _stream())
         nsm = _lib.load().svae_proj_ns_max()
         args = (w["h2s"].data_ptr() + 2 * DP * r0, w["h2b"].data_ptr() + 2 * DP * r0, self.w3b.data_ptr(),
-                self.w3tb.data_ptr(), self.IPAD, w["d1"].data_ptr() + 4 * DP * r0,
+                _lib.ptr(self.w3tb), self.IPAD, w["d1"].data_ptr() + 4 * DP * r0,
                 self.P("decoder.linear2.weight").data_ptr(), self.P("decoder.linear2.bias").data_ptr(),
                 plan.tgt.data_ptr() + 4 * plan.K * r0, plan.w_nll.data_ptr() + 4 * r0, n, self.I, plan.K,
                 w["pslabs"].data_ptr() + 4 * nsm * DP * r0, w["mpart"].data_ptr() + 4 * nsm * r0,
@@ -661,14 +662,14 @@ class SVAEEngine:
     def _proj_prep_items(self, st):
         _lib.call("svae_proj_prep_items_split", self.P("decoder.linear2.weight").data_ptr(),
                   self.P("decoder.linear2.bias").data_ptr(), self.I, self.IPAD, self.w3b.data_ptr(),
-                  self.w3s.data_ptr(), self.w3tb.data_ptr(), self._ps("items"), st)
+                  self.w3s.data_ptr(), _lib.ptr(self.w3tb), self._ps("items"), st)
 
     def _proj_prepare(self, R):
         """bf16 operand copies of the decoder hidden rows for the fused projection kernels."""
         w, st = self.ws, _stream()
         Rp = (R + 63) // 64 * 64
         _lib.call("svae_proj_prep_rows_range_split", w["d1"].data_ptr(), R, Rp, 0, Rp, w["h2b"].data_ptr(),
-                  w["h2s"].data_ptr(), w["h2tb"].data_ptr(), self._ps("rows"), st)
+                  w["h2s"].data_ptr(), _lib.ptr(w["h2tb"]), self._ps("rows"), st)
 
     def dense_logits(self, rows_idx=None):
         """Dense logits [n, I] for all rows of the last forward (rows_idx None) or a gathered subset
@@ -720,7 +721,7 @@ class SVAEEngine:
             Rp = (R + 63) // 64 * 64
 
             def proj_dw(slabs):
-                args = (self.w3s.data_ptr(), w["h2b"].data_ptr(), w["h2tb"].data_ptr(), R, Rp, I, IP,
+                args = (self.w3s.data_ptr(), w["h2b"].data_ptr(), _lib.ptr(w["h2tb"]), R, Rp, I, IP,
                         w["d1"].data_ptr(), plan.w_nll.data_ptr(), plan.occ_off.data_ptr(), plan.occ_row.data_ptr(),
                         plan.occ_items.data_ptr(), plan.nocc_long, slabs.data_ptr(),
                         self.Gv("decoder.linear2.weight").data_ptr(),
