@@ -7,6 +7,12 @@
 // Here the fp32 operand tiles go to LDS untouched by LDS-DMA (buffer_load ... lds: rows beyond R read as 0),
 // three tiles in flight per block; a wave builds its bf16 fragments from the row-major tile with conflict-free
 // column reads (lanes = consecutive columns) -- no staging registers, no transposing stores.
+//
+// What bounds it now (round 2, rocprofv3 + a rewrite that did not pay): a form of the bf16-dY kernel with both
+// operands staged as bf16 images and fragments from ds_read_b64_tr_b16 -- 16 LDS reads per 8 MFMAs instead of 64 reads
+// and 32 packs -- ran in the same 24 us (dW_ih, 24k rows).  The kernel moves bytes, not fragments: with 128 x 128
+// output tiles dY is read twice and X six times, 64 + 147 MB from L2 per launch, 8.8 TB/s in those 24 us, plus the
+// 2 x 22 MB of the slabs.  The next step would be fewer re-reads (256 x 128 tiles, bf16 copies of X), not a faster loop.
 #include "common.h"
 
 namespace {
