@@ -454,6 +454,7 @@ __device__ __forceinline__ void topk_radix_select(KeyAt key_at, int n, int K, in
 }
 
 constexpr int TOPK_NCAND = 4096;
+constexpr int TOPK_RV4 = 6;                // float4 per thread of the register-resident row: 24 576 items
 constexpr int TOPK_MASKW = 4096;           // 131 072 items
 
 __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restrict__ scores, int ld,
@@ -515,9 +516,32 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
         return;
     }
     // ---- pre-filter.  The K-th largest of the 1024 per-thread maxima is a lower bound of the K-th largest score
-    // (at least K scores reach it), and with scores dealt to threads round-robin only a few hundred do: the exact
+    // (at least K scores reach it), and with scores dealt to threads in small runs only a few hundred do: the exact
     // selection then runs over those in LDS instead of histogramming every score four times.
-    {
+    // Catalogues up to 4096 * TOPK_RV4 items: the row is read from HBM ONCE, 16 bytes per lane, and stays in registers
+    // (as sort keys, seen items already pushed down) for both passes -- before, the maxima pass and the filter pass
+    // each read it with 4-byte loads (the second time from L2).
+    const bool in_regs = lds_mask && I <= 4096 * TOPK_RV4 && (ld & 3) == 0 && ((uintptr_t)scores & 15) == 0;   // uniform
+    unsigned keys[TOPK_RV4][4];
+    if (in_regs) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int j = 0; j < TOPK_RV4; ++j) {
+            const int i4 = 4 * (tid + 1024 * j);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i4 < I) v = *reinterpret_cast<const float4*>(s + i4);       // (ld % 4 == 0: the 16 bytes are in the row)
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            const unsigned mw = i4 < I ? maskw[i4 >> 5] >> (i4 & 31) : 0u;   // 4 | i4: the four bits share a word
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float x = ((mw >> c) & 1u) ? e[c] - fabsf(e[c] * 1.0f) * 100000000.0f : e[c];
+                const unsigned k = i4 + c < I ? topk_key(x) : 0u;           // beyond the row: below every key
+                keys[j][c] = k;
+                m = k > m ? k : m;
+            }
+        }
+        tk[tid] = m;
+    } else {
         unsigned m = 0u;
         for (int i = tid; i < I; i += 1024) { const unsigned k = topk_key(val(i)); m = k > m ? k : m; }
         tk[tid] = m;
@@ -525,11 +549,24 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
     __syncthreads();
     topk_radix_select([&](int i) { return tk[i]; }, 1024, K, hist, &s_prefix, &s_remaining);
     const unsigned bound = s_prefix;
-    for (int i = tid; i < I; i += 1024) {
-        const unsigned k = topk_key(val(i));
-        if (k >= bound) {
-            const int pos = atomicAdd(&s_ncand, 1);
-            if (pos < TOPK_NCAND) { candk[pos] = k; candi[pos] = i; }
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < TOPK_RV4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = 4 * (tid + 1024 * j) + c;
+                if (i < I && keys[j][c] >= bound) {
+                    const int pos = atomicAdd(&s_ncand, 1);
+                    if (pos < TOPK_NCAND) { candk[pos] = keys[j][c]; candi[pos] = i; }
+                }
+            }
+    } else {
+        for (int i = tid; i < I; i += 1024) {
+            const unsigned k = topk_key(val(i));
+            if (k >= bound) {
+                const int pos = atomicAdd(&s_ncand, 1);
+                if (pos < TOPK_NCAND) { candk[pos] = k; candi[pos] = i; }
+            }
         }
     }
     __syncthreads();
