@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--items", type=int, default=None, help="catalogue size (default: the shape's)")
     ap.add_argument("--nplans", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sparse-embed", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: exchange the item-embedding gradient as (row id, row) pairs (auto: when fewer bytes)")
     ap.add_argument("--eval-leg", action="store_true", help="also time the scoring leg (forward + masked top-100)")
     ap.add_argument("--no-kernel-times", action="store_true", help="do not bracket kernels with events (no roofline)")
     ap.add_argument("--repeats", type=int, default=5,
@@ -126,6 +128,12 @@ def main():
         eng.prepare(p_)
     if world > 1 or rehearse:
         eng.grad_sync = GradSync(eng.grads, eng.layout.buckets(), force=rehearse)
+        # large catalogues: the item-embedding gradient (one non-zero row per distinct input item of the batch) goes
+        # over the wire as (row id, row) pairs when that is fewer bytes than the dense all-reduce of the table
+        cap_rows = max(p_.R for p_ in plans)
+        if args.sparse_embed == "on" or (args.sparse_embed == "auto" and GradSync.sparse_rows_pay(I, cap_rows, world)):
+            from svae_cf_amd.layout import E as _E
+            eng.grad_sync.enable_sparse_rows(2, I, _E, capacity=cap_rows)
 
     def barrier():
         torch.cuda.synchronize()
@@ -332,7 +340,7 @@ def main():
             "config": {"workload": "%s-shaped synthetic (configs[%d]): %d items, seq<=%d, "
                                    "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam"
                                    % (shape_name, shape_cfg, I, lmax, B),
-                       "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "mean_rows_bracketed_steps": rows_timed, "parallelism": "dp%d" % world,
+                       "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "mean_rows_bracketed_steps": rows_timed, "parallelism": "dp%d" % world, "embedding_gradient_exchange": ("rows" if (eng.grad_sync is not None and eng.grad_sync.sparse is not None) else "dense"),
                        "final_loss": loss, "side_stream": eng.side_stream_info},
             "kernel_ms": kt, "kernel_timing": "HIP events on the launch streams over a replay of the first %d timed steps "
                                              "(events inside the timed region stall the launch pipeline)" % replay_steps, "roofline": roofline, "rooflines": rooflines,

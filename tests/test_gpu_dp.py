@@ -31,7 +31,7 @@ def _init_sd(layout):
     return {n: torch.randn(s, generator=g) * 0.1 for n, s in layout.ref_shapes.items()}
 
 
-def _run(rank, world, prec, port, q, opt="adam"):
+def _run(rank, world, prec, port, q, opt="adam", sparse=False):
     sys.path.insert(0, ROOT)
     if q is not None:
         # a rank that stops making progress dumps its stacks and exits instead of hanging the test run
@@ -56,6 +56,9 @@ def _run(rank, world, prec, port, q, opt="adam"):
     mine = rank_batches(lens, B, np.random.default_rng(11), rank, WORLD) if world > 1 else None
     if world > 1:
         eng.grad_sync = GradSync(eng.grads, eng.layout.buckets())
+        if sparse:      # the item-embedding gradient as (row id, row) pairs: the large-catalogue exchange
+            from svae_cf_amd.layout import E
+            eng.grad_sync.enable_sparse_rows(2, I, E, capacity=max(len(u) for u in users) * B)
     losses = []
     for s in range(STEPS):
         idx = mine[s] if world > 1 else np.concatenate(steps[s])
@@ -83,14 +86,15 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("prec,opt", [(0, "adam"), (1, "adam"), (0, "adagrad")])
-def test_two_ranks_equal_union_batch(prec, opt):
+@pytest.mark.parametrize("prec,opt,sparse", [(0, "adam", False), (1, "adam", False), (0, "adagrad", False),
+                                             (0, "adam", True)])
+def test_two_ranks_equal_union_batch(prec, opt, sparse):
     import torch.multiprocessing as mp
     ref_sd, ref_losses = _run(0, 1, prec, 0, None, opt)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_run, args=(r, WORLD, prec, port, q, opt), daemon=True) for r in range(WORLD)]
+    ps = [ctx.Process(target=_run, args=(r, WORLD, prec, port, q, opt, sparse), daemon=True) for r in range(WORLD)]
     for p in ps:
         p.start()
     try:

@@ -12,7 +12,9 @@ import svae_cf_amd as S
 from svae_cf_amd import synth, notebook_api as N
 from svae_cf_amd.batch import build_plan
 
-workers = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+workers = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if os.environ.get("SVAE_SWITCH_INTERVAL"):
+    sys.setswitchinterval(float(os.environ["SVAE_SWITCH_INTERVAL"]))
 _, I, mu, sigma, lmax = synth.SHAPES["ml-20m"]
 B, NB = 256, int(os.environ.get('SVAE_EPOCH_BATCHES', '256'))
 users = synth.make_users(B * NB, I, mu, sigma, lmax, seed=98765)
