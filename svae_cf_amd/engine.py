@@ -593,10 +593,13 @@ class SVAEEngine:
                 tab, q, rem = _lib.proj_schedule(plan.R if nx is None else nx, self.I, ncu,
                                                  uniform=-int(os.environ.get("SVAE_FDH_Q0", "4")))
             else:
-                # uniform 4-way split.  With the sweep on its own stream past the end of the step, fewer and longer
-                # workgroups win (slab traffic): 2: 249.4k, 3: 248.9k, 4: 249.0k, 5: 247.6k, 6: 248.4k, 7: 245.1k,
-                # 8: 244.5k seq/s.  (Before the sweep floated, 8 was best: 3: -4 %, 4: -0.4 %.)
-                fq = int(os.environ.get("SVAE_DW_Q", "4"))
+                # uniform 2-way split.  With the sweep on its own stream past the end of the step, fewer and longer
+                # workgroups win (slab traffic, and CUs left to the kernels beside it).  Round 1: 2: 249.4k, 3: 248.9k,
+                # 4: 249.0k, 5: 247.6k, 6: 248.4k, 7: 245.1k, 8: 244.5k seq/s (before the sweep floated, 8 was best).
+                # Round 2, pipelined kernel (median ms per step over repeated regions): 1: 1.003, 2: 0.934, 3: 0.946,
+                # 4: 0.945, 5: 0.959, 6: 0.949, 8: 0.967 -- at 2 the 158 workgroups leave 98 CUs to the BPTT and the
+                # weight-gradient GEMMs (0.36 -> 0.27 ms) and write half the slabs of the 4-way split.
+                fq = int(os.environ.get("SVAE_DW_Q", "2"))
                 tab, q, rem = _lib.proj_schedule(self.I, plan.R, ncu, uniform=1 + fq)   # (ncu unused: uniform)
             if host_only:
                 return key, tab, q, rem
