@@ -308,7 +308,9 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     //  partners run A beside B: 3297 -> 3202 cycles per tile in the DW sweep, and 95 spilled registers in the FDH one,
     //  whose mid-iteration barrier keeps the logits alive across it; a barrier every other tile: 3194; issue priority
     //  (s_setprio) alternating between the two waves of a SIMD every half tile: the arrival spread at the barrier
-    //  falls from ~650 to ~250 cycles, the tile takes as long as before.  None kept.)
+    //  falls from ~650 to ~250 cycles, the tile takes as long as before; one barrier per PAIR of tiles with eight
+    //  stages, tile j+6 issued during tile j and the third piece alternating between the wave halves with the tile's
+    //  parity (five pieces per wave between two barriers): correct, 2 % slower on both sweeps.  None kept.)
     constexpr int W = 4;
     constexpr int PSTAGE = YIMG_BYTES;
     constexpr int NSTP = 7;                       // stages; tile j+NSTP-2 is issued during tile j, into tile j-2's stage
