@@ -136,6 +136,7 @@ class SVAEEngine:
         self._w3_event = None          # recorded on the w3 stream behind the floated work of the last train_step
         self._w3_fresh = False         # w3b / w3s / w3tb match the current parameters (made by the floated work)
         self.tail_embedding_first = os.environ.get("SVAE_TAIL", "emb") == "emb"
+        self.gru_wgrad_side = os.environ.get("SVAE_GRU_WGRAD_SIDE", "1") == "1"
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.event_pool = []
         self.timer_pool = []
@@ -850,12 +851,24 @@ class SVAEEngine:
                 self._bucket(2)
 
         def gru_wgrads():
-            # (Tried: these two on a second side stream beside dL/demb -> scatter-add.  2.5 % SLOWER, 1.153 vs 1.123 ms
-            # per step: the tail of backward is short of bandwidth, not of parallelism.)
+            # (Round 1: these two on a THIRD stream beside dL/demb -> scatter-add were 2.5 % slower, 1.153 vs 1.123 ms per
+            # step.  Round 2: on the existing side stream, behind the dense-layer gradients, +1.4 %, 0.925 -> 0.911 ms: a
+            # kernel trace shows the caller's queue busy 898 of a step's 971 us -- it is the critical path, and by the
+            # end of the BPTT the side stream has been idle for ~70 us.)
             self._wgrad(dgh, w["hprev"], "gru.weight_hh_l0", R, G, HP, ldg, HP, remap=hh_remap, dy_bf16=dg16)
             self._wgrad(dgi, w["emb"], "gru.weight_ih_l0", R, G, E, ldg, E, dy_bf16=dg16)
 
-        if self.tail_embedding_first:
+        if side is not None and self.gru_wgrad_side:
+            # the two GRU weight gradients behind the dense-layer ones on the side stream (idle by the time the BPTT
+            # ends), beside dL/demb -> scatter-add on the caller's: the caller's queue is the step's critical path
+            # (host order: the caller's kernels first -- its queue must not run dry while the side launches are made)
+            bptt_done = torch.cuda.Event()
+            bptt_done.record(cur)
+            embedding_grad()
+            side.wait_event(bptt_done)
+            with _Launch(side, self._torch_ctx()):
+                gru_wgrads()          # (one of the two here and one on the caller's stream: no better, 0.922 vs 0.918)
+        elif self.tail_embedding_first:
             embedding_grad()
             gru_wgrads()
         else:
