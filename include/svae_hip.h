@@ -96,6 +96,14 @@ int svae_gru_fwd_range(const float* gi, const float* whh, const float* bhh, cons
 /* the same with bf16 elements (every consumer rounds to bf16 anyway): svae_rowgemm_bf16x / svae_wgrad_cols_bf16dy */
 int svae_gru_bwd_bf16out(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
                          const int* row_off, const int* nact, int B, int Tmax, void* dg4, void* stream);
+/* The BPTT over timesteps [t0, t1) only (it runs from t1-1 down to t0; bf16 kernel, merged bf16 gradient array).
+ * t1 < Tmax continues a BPTT whose steps >= t1 have been run with the same dh_carry [B][224] fp32; t0 > 0 leaves the
+ * recurrent part of dL/dh_{t0-1} there.  When the call has run, the rows of timesteps >= t0 of dg4 are final.  No
+ * counterpart in the reference (one autograd call, nb:1205): the split lets the weight and embedding gradients of the
+ * late timesteps' rows start while the BPTT of the early ones is still running. */
+int svae_gru_bwd_range_bf16out(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
+                               const int* row_off, const int* nact, int B, int Tmax, int t0, int t1, void* dg4,
+                               float* dh_carry, void* stream);
 int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t, const int* row_off,
                  const int* nact, int B, int Tmax, float* dgi, float* dgh, int prec, void* stream);
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "svae_rowgemm_bf16x": [_P, _I, _P, _P, _I, _P],
     "svae_wgrad_cols_bf16dy": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _LL, _I, _I, _P],
     "svae_gru_bwd_bf16out": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
+    "svae_gru_bwd_range_bf16out": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "svae_rowgemm_ld": [_P, _I, _P, _P, _P, _I, _I, _P],
     "svae_wgrad_cols": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _LL, _I, _I, _P],
     "svae_zero": [_P, _LL, _P],

@@ -71,7 +71,9 @@ struct GruArgs {
     int B, Tmax;
     int merged;           // backward, bf16 kernel: dgi is ONE array [R][4*224] = (dr, dz, dn, dn*r); dgh is unused
                           // (1: fp32 elements, 2: bf16 elements)
-    int t0, t1;           // forward, bf16 kernel: timesteps [t0, t1) of the recurrence (t0 > 0: h_{t0-1} is read from hs)
+    int t0, t1;           // bf16 kernels: timesteps [t0, t1).  Forward: t0 > 0 continues from hs (h_{t0-1}).  Backward
+                          // (runs t1-1 down to t0): t1 < Tmax continues from dh_carry, t0 > 0 leaves dL/dh_{t0-1} there
+    float* dh_carry;      // [B][224]  backward only: the recurrent part of dL/dh across a range boundary
 };
 
 // forward gate math for one owned element; returns h_t
@@ -639,8 +641,15 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
             sdh[q] = __builtin_amdgcn_raw_buffer_load_b32(dh_b, ohs + 512 * q, 0, 0);                       \
         }                                                                                                   \
     }
-    if (Tw > 0) SV_GRU_BWD_FETCH(Tw - 1)
-    for (int t = Tw - 1; t >= 0; --t) {
+    // Range [t0, t1) of the BPTT (a whole recurrence: 0, Tmax).  A later range has left the recurrent part of
+    // dL/dh_{t1-1} of the users still running at step t1 in dh_carry; this one leaves dL/dh_{t0-1} there.
+    const int t_hi = Tw < a.t1 ? Tw : a.t1;
+    if (a.t1 < a.Tmax && lk < MU && u0 + lk < nact_s[a.t1]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dh[q] = a.dh_carry[(size_t)(u0 + lk) * SV_HP + 16 * (wave + 8 * q) + ln];
+    }
+    if (t_hi > a.t0) SV_GRU_BWD_FETCH(t_hi - 1)
+    for (int t = t_hi - 1; t >= a.t0; --t) {
         unsigned short* gcur = g_bf + (t & 1) * (MU * GLDB);
         float carry[NQ];
 #pragma unroll
@@ -715,6 +724,10 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (a.t0 > 0 && t_hi > a.t0 && lk < MU && u0 + lk < a.B) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) a.dh_carry[(size_t)(u0 + lk) * SV_HP + 16 * (wave + 8 * q) + ln] = dh[q];
+    }
 #undef SV_GRU_BWD_FETCH
 }
 
@@ -787,18 +800,43 @@ extern "C" int svae_gru_bwd_bf16out(const float* dhs, const float* hprev, const 
     return svae_gru_bwd(dhs, hprev, gates4, whh_t, row_off, nact, B, Tmax, (float*)dg4, nullptr, 3, stream);
 }
 
+static int gru_bwd_launch(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
+                          const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dgh, int prec,
+                          int t0, int t1, float* dh_carry, void* stream);
+
 // Reference interface replaced: autograd through nn.GRU at loss.backward() (nb:1205).
 // whh_t is W_hh transposed, [224][672].
 extern "C" int svae_gru_bwd(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
                             const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dgh,
                             int prec, void* stream) {
+    return gru_bwd_launch(dhs, hprev, gates4, whh_t, row_off, nact, B, Tmax, dgi, dgh, prec, 0, Tmax, nullptr, stream);
+}
+
+// The BPTT over timesteps [t0, t1) only (it runs from t1-1 down to t0), bf16 kernel, merged bf16 gradient array.
+// t1 < Tmax continues a BPTT whose steps >= t1 have been run with the same dh_carry [B][224]; t0 > 0 leaves the
+// recurrent part of dL/dh_{t0-1} there for the next call.  The rows of timesteps >= t0 of dg4 are final when the call
+// has run.  No counterpart in the reference (one autograd call there): the split lets the host start the weight and
+// embedding gradients of the late timesteps' rows while the BPTT of the early ones is still running.
+extern "C" int svae_gru_bwd_range_bf16out(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
+                                          const int* row_off, const int* nact, int B, int Tmax, int t0, int t1,
+                                          void* dg4, float* dh_carry, void* stream) {
+    SV_CHECK_ARG(t0 >= 0 && t0 < t1 && t1 <= Tmax, "svae_gru_bwd_range: bad range [%d, %d) of %d", t0, t1, Tmax);
+    SV_CHECK_ARG(dh_carry || (t0 == 0 && t1 == Tmax), "svae_gru_bwd_range: a partial range needs dh_carry");
+    return gru_bwd_launch(dhs, hprev, gates4, whh_t, row_off, nact, B, Tmax, (float*)dg4, nullptr, 3, t0, t1, dh_carry,
+                          stream);
+}
+
+static int gru_bwd_launch(const float* dhs, const float* hprev, const float* gates4, const float* whh_t,
+                          const int* row_off, const int* nact, int B, int Tmax, float* dgi, float* dgh, int prec,
+                          int t0, int t1, float* dh_carry, void* stream) {
     // dgh == NULL (bf16 kernel only): merged output, dgi is [R][896] = (dr, dz, dn, dn*r)
     const int out16 = prec == 3 ? 1 : 0;      // internal: svae_gru_bwd_bf16out
     if (out16) prec = 1;
     const int merged = dgh == nullptr ? 1 + out16 : 0;
     GruArgs a{nullptr, whh_t, nullptr, row_off, nact, nullptr, const_cast<float*>(hprev),
-              const_cast<float*>(gates4), dhs, dgi, merged ? dgi : dgh, B, Tmax, merged, 0, Tmax};
+              const_cast<float*>(gates4), dhs, dgi, merged ? dgi : dgh, B, Tmax, merged, t0, t1, dh_carry};
     if (int e = check_gru(a, true)) return e;
+    SV_CHECK_ARG(prec == 1 || (t0 == 0 && t1 == Tmax), "svae_gru_bwd: time ranges need the bf16 kernel");
     SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gru_bwd: bad prec %d", prec);
     SV_CHECK_ARG(!merged || prec == 1, "svae_gru_bwd: the merged gradient array needs the bf16 kernel");
     dim3 grid((B + MB - 1) / MB);

@@ -101,6 +101,8 @@ class SVAEEngine:
         self.nsplit = int(os.environ.get("SVAE_NSPLIT", "32"))   # row splits of the weight-gradient GEMMs
         self.slabs = torch.zeros(self.nsplit * (G * E + G), **f32)        # largest split-K output: dW_ih
         self.slabs_side = torch.zeros(self.nsplit * (DP * HP + DP), **f32)  # side-stream weight gradients
+        self.slabs_hh = None                 # (two-range BPTT: dW_hh's slabs stay pending beside dW_ih's)
+        self.dh_carry = None
         # Backward runs on two streams: the data-gradient chain that leads to the GRU's BPTT (a 16-64 CU kernel,
         # latency bound) stays on the caller's stream, the decoder-side weight gradients (whole-GPU kernels that
         # nothing downstream waits for) go to a side stream and fill the CUs the recurrence leaves idle.
@@ -138,6 +140,7 @@ class SVAEEngine:
         self.tail_embedding_first = os.environ.get("SVAE_TAIL", "emb") == "emb"
         self.gru_wgrad_side = os.environ.get("SVAE_GRU_WGRAD_SIDE", "1") == "1"
         self.gi_split = os.environ.get("SVAE_GI_SPLIT", "1") == "1"
+        self.bptt_split = os.environ.get("SVAE_BPTT_SPLIT", "0") == "1"
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.event_pool = []
         self.timer_pool = []
@@ -804,7 +807,30 @@ class SVAEEngine:
         dg16 = merged and self.dg_bf16 and prepped
         dgi, ldg = (w["dg4b"] if dg16 else w["dg4"], 4 * HP) if merged else (w["dgi"], G)
         dgh, hh_remap = (dgi, (2 * HP, HP)) if merged else (w["dgh"], None)
-        if dg16:
+        # Two-range BPTT (as the forward's two ranges, the other way round): the recurrence runs from the last timestep
+        # down, so the rows of the timesteps >= tb are final first -- their share of the GRU weight gradients and of
+        # dL/demb runs on the side stream while the BPTT of the steps < tb is still going.  OFF by default
+        # (SVAE_BPTT_SPLIT=1): correct (tests/test_gpu_fullsize.py), and 5 % slower, 0.897 -> 0.947 ms per step -- a
+        # kernel trace shows why: two BPTT launches cost 131 us where one costs 108 (each loads the 300 KB of W_hh
+        # fragments and ramps up), the side stream is still busy with the dense-layer gradients when the late rows
+        # become final, and four half-size weight-gradient launches + their reduces take longer than two whole ones.
+        tb = rb = 0
+        if (dg16 and side is not None and self.bptt_split and self.gru_wgrad_side and plan.split_t > 0
+                and self.fused and self.rowgemm and prepped):
+            tb = int(plan.split_t)
+            rb = (int(plan._row_off_host[tb]) + 63) // 64 * 64
+            if rb < 2048 or R - rb < 2048:
+                tb = rb = 0
+        if tb:
+            if self.dh_carry is None or self.dh_carry.numel() < plan.B * HP:
+                self.dh_carry = torch.zeros(max(plan.B, 256) * HP, device=self.device, dtype=torch.float32)
+            gargs = (w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(), self.whh_t.data_ptr(),
+                     plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax)
+            _lib.call("svae_gru_bwd_range_bf16out", *gargs, tb, plan.Tmax, dgi.data_ptr(), self.dh_carry.data_ptr(), st)
+            late_done = torch.cuda.Event()
+            late_done.record(cur)
+            _lib.call("svae_gru_bwd_range_bf16out", *gargs, 0, tb, dgi.data_ptr(), self.dh_carry.data_ptr(), st)
+        elif dg16:
             _lib.call("svae_gru_bwd_bf16out", w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
                       self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
                       dgi.data_ptr(), st)
@@ -875,7 +901,9 @@ class SVAEEngine:
             self._wgrad(dgh, w["hprev"], "gru.weight_hh_l0", R, G, HP, ldg, HP, remap=hh_remap, dy_bf16=dg16)
             self._wgrad(dgi, w["emb"], "gru.weight_ih_l0", R, G, E, ldg, E, dy_bf16=dg16)
 
-        if side is not None and self.gru_wgrad_side:
+        if tb:
+            self._tail_two_ranges(plan, cur, side, late_done, dgi, ldg, rb, hh_remap)
+        elif side is not None and self.gru_wgrad_side:
             # the two GRU weight gradients behind the dense-layer ones on the side stream (idle by the time the BPTT
             # ends), beside dL/demb -> scatter-add on the caller's: the caller's queue is the step's critical path
             # (host order: the caller's kernels first -- its queue must not run dry while the side launches are made)
@@ -898,6 +926,60 @@ class SVAEEngine:
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
         self._loss_deferred = False
         self._bucket(1)      # dense layers (side stream) + GRU (this stream): behind the join
+
+    def _tail_two_ranges(self, plan, cur, side, late_done, dg, ldg, rb, hh_remap):
+        """Tail of backward with a two-range BPTT (bf16 gradient array dg [R][ldg]): rows >= rb were final at
+        `late_done` (recorded on `cur` between the two BPTT launches), the others are when `cur` reaches this point.
+        Row ranges of one weight gradient write disjoint slab sets that ONE reduce sums at the end."""
+        w, R = self.ws, plan.R
+        ns = max(2, min(self.nsplit, (R + 127) // 128))
+        ns_a = max(1, min(ns - 1, int(round(ns * (R - rb) / float(R)))))
+        if self.slabs_hh is None:
+            self.slabs_hh = torch.zeros(self.nsplit * (G * HP + G), device=self.device, dtype=torch.float32)
+        jobs = (("gru.weight_hh_l0", w["hprev"], HP, self.slabs_hh, hh_remap),
+                ("gru.weight_ih_l0", w["emb"], E, self.slabs, ((G + 7) // 8 * 8, 0)))
+
+        def wgrads(r0, r1, z0, nz):
+            for name, X, K, slabs, (rf, ra) in jobs:
+                stride = G * K + G
+                sp = slabs.data_ptr() + 4 * stride * z0
+                ev = self._tic("wgrad")
+                _lib.call("svae_wgrad_cols_bf16dy", dg.data_ptr() + 2 * ldg * r0, X.data_ptr() + 4 * K * r0, sp,
+                          sp + 4 * G * K, r1 - r0, G, K, ldg, K, nz, stride, rf, ra, _stream())
+                self._toc("wgrad", ev)
+
+        def demb(r0, r1):
+            ev = self._tic("demb_gemm")
+            _lib.call("svae_rowgemm_bf16x", dg.data_ptr() + 2 * ldg * r0, ldg, self.wih_frags[1].data_ptr(),
+                      w["demb"].data_ptr() + 4 * E * r0, r1 - r0, _stream())
+            self._toc("demb_gemm", ev)
+
+        early_done = torch.cuda.Event()
+        early_done.record(cur)
+        demb(0, rb)                                   # the caller's stream: rows of the early timesteps
+        side.wait_event(late_done)
+        with _Launch(side, self._torch_ctx()):
+            demb(rb, R)
+            late_demb = torch.cuda.Event()
+            late_demb.record(side)
+            wgrads(rb, R, 0, ns_a)
+        cur.wait_event(late_demb)
+        ge = self.Gv("item_embed.weight")
+        self._prepped_grad = False
+        _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
+                  plan.seg_item.data_ptr(), ge.data_ptr(), plan.nseg, plan.nseg_long, 1.0, _stream())
+        gs = self.grad_sync
+        if gs is not None and gs.sparse is not None and gs.sparse["bucket"] == 2:
+            gs.rows_ready(plan.seg_item, plan.nseg)
+        else:
+            self._bucket(2)
+        side.wait_event(early_done)
+        with _Launch(side, self._torch_ctx()):
+            wgrads(0, rb, ns_a, ns - ns_a)
+            for name, X, K, slabs, _ in jobs:
+                stride = G * K + G
+                _lib.call("svae_reduce_slabs", slabs.data_ptr(), self._gbase + 4 * self.layout.offset(name), stride, ns,
+                          stride, _stream())
 
     # ------------------------------------------------------------------ dense (notebook) surface
     def dense_loss(self, logits, mu, ls, tgt, anneal, batch_size=1.0):

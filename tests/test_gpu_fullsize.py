@@ -221,3 +221,36 @@ def test_fused_operand_copies_equal_the_two_kernel_path():
                           h2b=eng.ws["h2b"][:Rp * 160].clone(), h2s=eng.ws["h2s"][:Rp * 160].clone())
     for k in got[False]:
         assert torch.equal(got[False][k], got[True][k]), k
+
+
+def test_two_range_bptt_equals_one_launch():
+    """svae_gru_bwd_range_bf16out: the BPTT as two launches (timesteps >= tb, then < tb, the recurrent part of dL/dh
+    handed over in dh_carry) against the single launch, on an ML-20M-shaped batch with a time split: the gate-gradient
+    array bit-identical; the gradients equal up to the summation order of the weight gradients' row slabs (the two
+    row ranges write disjoint slab sets)."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    I, B = 20000, 256
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(2048, I, mu, sigma, lmax, seed=4242)
+    plan = None
+    for cand in synth.bucketed_batches([len(u) for u in users], B, np.random.default_rng(2)):
+        p = S.build_plan([users[i] for i in cand], 4, user_keys=cand, device="cuda", total_items=I)
+        if p.split_t > 0 and p.R % 64 != 0:
+            plan = p
+            break
+    assert plan is not None
+    got = {}
+    for split in (False, True):
+        eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+        _init(eng, 5)
+        eng.bptt_split = split
+        eng.prepare(plan)
+        eng.forward(plan, 0.05, seed=9, step=2)
+        eng.backward()
+        torch.cuda.synchronize()
+        got[split] = (eng.ws["dg4b"][:plan.R * 896].clone(), eng.grad_dict())
+    assert torch.equal(got[False][0], got[True][0])
+    for k in got[False][1]:
+        a, b = got[True][1][k], got[False][1][k]
+        assert _l2(a, b) <= 2e-6, (k, _l2(a, b))
