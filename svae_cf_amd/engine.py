@@ -413,13 +413,6 @@ class SVAEEngine:
             # zero fill of the embedding gradient) runs on the side stream beside the embedding / GRU kernels
             side.wait_event(step_begin)
             with _Launch(side, self._torch_ctx()):
-                if gi_split:
-                    _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr() + 4 * gi_split,
-                              w["emb"].data_ptr() + 4 * E * gi_split, R - gi_split, self.I, _stream())
-                    side.wait_event(head_done)          # (the W_ih fragments)
-                    _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr() + 4 * E * gi_split, E,
-                              self.wih_frags[0].data_ptr(), self.P("gru.bias_ih_l0").data_ptr(),
-                              w["gi"].data_ptr() + 4 * G * gi_split, R - gi_split, 0, self.prec, _stream())
                 self._param_prep(want_grad)
                 if eps is None:               # the noise depends on the plan and the step only
                     _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
@@ -427,6 +420,15 @@ class SVAEEngine:
                     eps_done = True
                 params_ready = torch.cuda.Event()
                 params_ready.record(side)
+                if gi_split:
+                    # (behind the parameter preparation: the decoder side of the first range waits for that, the
+                    #  second recurrence, which needs these rows, only starts when the first one has ended)
+                    _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr() + 4 * gi_split,
+                              w["emb"].data_ptr() + 4 * E * gi_split, R - gi_split, self.I, _stream())
+                    side.wait_event(head_done)          # (the W_ih fragments)
+                    _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr() + 4 * E * gi_split, E,
+                              self.wih_frags[0].data_ptr(), self.P("gru.bias_ih_l0").data_ptr(),
+                              w["gi"].data_ptr() + 4 * G * gi_split, R - gi_split, 0, self.prec, _stream())
         # Two time ranges (batch.choose_time_split): the recurrence of steps >= t1 runs on the side stream beside
         # the decoder side of the rows of steps < t1 (rows are time-major: the first r1 of them).
         t1, r1 = (plan.split_t, plan.split_r) if (self.time_split and params_ready is not None and want_loss
