@@ -408,7 +408,32 @@ class SVAEEngine:
         else:
             self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
                        bias=self.P("gru.bias_ih_l0"))
-        if self.fused and self.overlap:
+        # Two time ranges (batch.choose_time_split): the recurrence of steps >= t1 runs on the side stream beside
+        # the decoder side of the rows of steps < t1 (rows are time-major: the first r1 of them).
+        side_prep = self.fused and self.overlap
+        t1, r1 = (plan.split_t, plan.split_r) if (self.time_split and side_prep and want_loss
+                                                  and want_grad and self.gru_prec == PREC_BF16) else (0, 0)
+
+        def gru_range(a, b, tag):
+            ev = self._tic(tag)
+            _lib.call("svae_gru_fwd_range", w["gi"].data_ptr(), self.P("gru.weight_hh_l0").data_ptr(),
+                      self.P("gru.bias_hh_l0").data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(),
+                      plan.B, plan.Tmax, a, b, w["hs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
+                      self.gru_prec, _stream())
+            self._toc(tag, ev)
+
+        # Host order = critical path first: the recurrence that heads the step is enqueued before the side stream's
+        # eight launches (when the host is not far ahead of the GPU -- the first steps of a run, a profiler attached,
+        # collectives in the step -- the caller's queue otherwise runs dry for as long as those take: 50-130 us in a
+        # kernel trace).
+        if t1 > 0:
+            gru_range(0, t1, "gru_fwd")
+            first_done = torch.cuda.Event()
+            first_done.record(cur)
+        else:
+            gru_range(0, plan.Tmax, "gru_fwd")
+        second_done = None
+        if side_prep:
             # everything that depends on the parameters only (bf16 operand copies, weight fragments, W_hh^T, the
             # zero fill of the embedding gradient) runs on the side stream beside the embedding / GRU kernels
             side.wait_event(step_begin)
@@ -429,31 +454,11 @@ class SVAEEngine:
                     _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr() + 4 * E * gi_split, E,
                               self.wih_frags[0].data_ptr(), self.P("gru.bias_ih_l0").data_ptr(),
                               w["gi"].data_ptr() + 4 * G * gi_split, R - gi_split, 0, self.prec, _stream())
-        # Two time ranges (batch.choose_time_split): the recurrence of steps >= t1 runs on the side stream beside
-        # the decoder side of the rows of steps < t1 (rows are time-major: the first r1 of them).
-        t1, r1 = (plan.split_t, plan.split_r) if (self.time_split and params_ready is not None and want_loss
-                                                  and want_grad and self.gru_prec == PREC_BF16) else (0, 0)
-
-        def gru_range(a, b, tag):
-            ev = self._tic(tag)
-            _lib.call("svae_gru_fwd_range", w["gi"].data_ptr(), self.P("gru.weight_hh_l0").data_ptr(),
-                      self.P("gru.bias_hh_l0").data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(),
-                      plan.B, plan.Tmax, a, b, w["hs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
-                      self.gru_prec, _stream())
-            self._toc(tag, ev)
-
-        second_done = None
-        if t1 > 0:
-            gru_range(0, t1, "gru_fwd")
-            first_done = torch.cuda.Event()
-            first_done.record(cur)
-            side.wait_event(first_done)
-            with _Launch(side, self._torch_ctx()):
-                gru_range(t1, plan.Tmax, "gru_fwd2")
-                second_done = torch.cuda.Event()
-                second_done.record(side)
-        else:
-            gru_range(0, plan.Tmax, "gru_fwd")
+                if t1 > 0:
+                    side.wait_event(first_done)
+                    gru_range(t1, plan.Tmax, "gru_fwd2")
+                    second_done = torch.cuda.Event()
+                    second_done.record(side)
         if eps is not None:
             if eps.numel() != R * L:
                 raise ValueError("eps must have %d x %d elements" % (R, L))

@@ -12,8 +12,10 @@ def short(n):
 # steps end with the LAST adam_kernel of a step (two per step: floated W3 bucket on its own queue + the rest)
 adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
 # the caller's queue = the queue of embed_fwd
-mainq = collections.Counter(r['Queue_Id'] for r in rows if 'embed_fwd' in r['Kernel_Name']).most_common(1)[0][0]
-starts = [i for i, r in enumerate(rows) if 'embed_fwd_kernel' in r['Kernel_Name']]
+mainq = collections.Counter(r['Queue_Id'] for r in rows if 'gru_bwd' in r['Kernel_Name']).most_common(1)[0][0]
+# a step starts with the first gather on the caller's queue (a second one, for the rows of the second time range, runs
+# on the side queue)
+starts = [i for i, r in enumerate(rows) if 'embed_fwd_kernel' in r['Kernel_Name'] and r['Queue_Id'] == mainq]
 starts = starts[len(starts) // 3:]                      # steady state
 spans, busy, gaps = [], collections.defaultdict(float), collections.defaultdict(float)
 n = 0
