@@ -193,6 +193,12 @@ class SVAEEngine:
         self.step_count = 0
 
     # ------------------------------------------------------------------ workspace
+    def reserve(self, max_rows):
+        """Size the workspace for batches of up to `max_rows` rows now.  It otherwise grows on demand, and growing is a
+        synchronisation plus a reallocation of every buffer in the middle of a run (seen in the driver's 20-step bench
+        of round 1: plans first met inside the timed region)."""
+        self._ensure(int(max_rows))
+
     def _ensure(self, R):
         if R <= self.cap:
             return

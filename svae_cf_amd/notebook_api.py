@@ -461,7 +461,10 @@ def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, 
             reader._svae_csr = csr
         except AttributeError:
             pass
-    batches = rank_batches(np.diff(csr[1].off), batch_size, rng, rank, world)
+    lens_all = np.diff(csr[1].off)
+    batches = rank_batches(lens_all, batch_size, rng, rank, world)
+    if len(batches):
+        eng.reserve(max(int(lens_all[np.asarray(b)].sum()) - len(b) for b in batches))   # rows = sum of (length - 1)
     plans = PlanPrefetcher(batches, csr[1], k, eng.device, total_items=eng.I, prepare=eng.prepare,
                            workers=workers, depth=4 * workers)
     for b, (idx, plan) in enumerate(zip(batches, plans), start=1):
