@@ -116,7 +116,14 @@ def load():
 _fns = {}
 
 
+# Timing experiments only (tools/skip_sensitivity.sh): entry points named in SVAE_SKIP are not called, so that the
+# step's sensitivity to each kernel can be read off the step time.  Results are then wrong by construction.
+_SKIP = frozenset(x for x in os.environ.get("SVAE_SKIP", "").split(",") if x)
+
+
 def call(name, *args):
+    if _SKIP and name in _SKIP:
+        return
     fn = _fns.get(name)
     if fn is None:
         fn = _fns[name] = getattr(load(), name)

@@ -320,6 +320,18 @@ __device__ __forceinline__ bf16x8 load_w8(const float* p) {
     return v;
 }
 
+// Re-deal of a 16x16 accumulator tile whose rows 0..3 are the real users (registers 0..3 of lanes 0..15): lane
+// 16 u + n receives row u, column n.  Two row swaps and one half swap in registers (gfx950's v_permlane16_swap /
+// v_permlane32_swap; semantics checked by tools/probe/permlane_probe.hip) instead of a round trip through an LDS
+// scratch (24 ds_write_b32 on 16 lanes, a wave barrier, 6 ds_read_b32 and their latencies on the step's chain).
+__device__ __forceinline__ float redeal_rows(const f32x4 c) {
+    // permlane16_swap(a, b)[0] = (a.row0, b.row0, a.row2, b.row2); permlane32_swap(a, b)[0] = (a.row0, a.row1, b.row0, b.row1)
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(c[0]), __float_as_uint(c[1]), false, false);
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(c[2]), __float_as_uint(c[3]), false, false);
+    const auto s = __builtin_amdgcn_permlane32_swap(p[0], q[0], false, false);
+    return __uint_as_float(s[0]);
+}
+
 // Register budget: a wave that owns 4 hidden tiles would need 336 registers for its W_hh fragments alone;
 // with the per-step prefetch (gi / saved gates) that spills.  So every wave keeps THREE tiles in registers
 // (252) and the fourth tile of waves 0 and 1 lives in LDS in fragment order (lane-linear 16-byte reads,
@@ -496,24 +508,12 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
         SV_TS(2)
 #undef SV_WLOAD
 #undef SV_PIN_ORDER
-        // re-deal: lanes 0..15 (rows 0..3 = the real users) publish, every lane picks its (user lk, unit ln) values
-        if (lk == 0) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xs[((q * 3 + g) * 4 + r) * 16 + ln] = acc[q][g][r];
-        }
-        // other LANES read what these stores wrote: the compiler only orders a thread's own aliasing accesses,
-        // so pin the order (the LDS itself executes a wave's instructions in order)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+        // re-deal: every lane picks its (user lk, unit ln) values out of rows 0..3 of the accumulator tiles
         float gh[NQ][3];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) gh[q][g] = xs[(q * 3 + g) * 64 + lane];
+            for (int g = 0; g < 3; ++g) gh[q][g] = redeal_rows(acc[q][g]);
 #ifdef SV_GRU_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -710,18 +710,8 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
                 }
             }
             // re-deal dh_{t-1} = carry + dgh W_hh: rows 0..3 of the C tile (lanes 0..15) -> lane 16 u + n
-            if (lk == 0) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xs[(q * 4 + r) * 16 + ln] = acc[q][r];
-            }
-            asm volatile("" ::: "memory");      // read by other lanes: keep the compiler from reordering
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) dh[q] = carry[q] + xs[q * 64 + lane];
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
+            for (int q = 0; q < NQ; ++q) dh[q] = carry[q] + redeal_rows(acc[q]);
         }
     }
     if (a.t0 > 0 && t_hi > a.t0 && lk < MU && u0 + lk < a.B) {

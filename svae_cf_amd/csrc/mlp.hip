@@ -17,6 +17,13 @@
 // As separate launches of the generic GEMM these were 8 latency-bound kernels of 35-40 us each.
 #include "common.h"
 
+#ifdef SV_MLP_TIMING
+// diagnostic build only (-DSV_MLP_TIMING, read by tools/probe/mlp_time.py): phase stamps of workgroup 0, wave 0
+__device__ unsigned long long g_mlp_dbg[8];
+#define SV_MTS(i_) { __builtin_amdgcn_sched_barrier(0); ts_[i_] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define SV_MTS(i_)
+#endif
 namespace {
 
 constexpr int KS_H = SV_HP / 16;    // 14 k-steps over the GRU state
@@ -142,6 +149,21 @@ __device__ __forceinline__ void stage_frags(const unsigned short* frags, int fir
 constexpr int NFRAG_FWD = OFF_B1 - OFF_F1;     // 130
 constexpr int NFRAG_BWD = NFRAG - OFF_B1;      // 130
 constexpr int MLP_ROWS = 128;                  // rows per block (4 waves x 32)
+// Behind the forward kernel's fragments: the three bias vectors (b1 [160], bl [128], b2 [160]) as floats.  Every
+// accumulator tile starts from its bias; read from global memory in front of each tile, that load sits BEHIND the
+// stores of the tile before it in the wave's one in-order memory counter, so every tile waited for an HBM write
+// acknowledgement.  The kernels now issue every global load before their first store and never wait for a store
+// (a lone workgroup: 20.3 -> 17.8 us forward, 170 workgroups 25.7 -> 22.8 us; tools/probe/mlp_time.py).
+// What the rest is (SV_MLP_TIMING stamps, cycles of one wave): 12k until the fragments and rows are there (two
+// memory round trips' worth, the 130 KiB LDS-DMA per workgroup), then 9k / 7k / 13k for the three layers, which is
+// the wave's own vector work -- 352 transcendentals (tanh = exp + rcp, quarter rate) and ~2000 other vector
+// instructions for 32 rows, one wave per SIMD.  Tried on top, no gain, not kept: the tiles stored as whole
+// 128-byte row segments through an LDS transpose (a direct store touches 32 rows per instruction; 18.6 us), and the
+// fragments of a k-loop read one tile ahead instead of ds_read -> wait -> MFMA per k-step (18.5 us).  Halving the
+// rows per SIMD (64-row workgroups) is what would shorten it; the backward's 21.8k rows then need two rounds.
+constexpr int BIAS_FLOATS = SV_DP + SV_L2 + SV_DP;
+constexpr int MLP_FWD_LDS = NFRAG_FWD * 1024 + BIAS_FLOATS * 4;
+constexpr int BOFF_1 = 0, BOFF_L = SV_DP, BOFF_2 = SV_DP + SV_L2;
 // natural-order B fragment from an fp32 row: 8 consecutive floats
 template <bool SPLIT>
 __device__ __forceinline__ B3 row_frag(const float* p) {
@@ -236,18 +258,40 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
     const bool ok = r < a.R && (!PREP || r < a.row1);
     const size_t rc = ok ? r : a.R - 1;          // loads are clamped, stores masked
 
+#ifdef SV_MLP_TIMING
+    unsigned long long ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // ---- encoder: enc^T = tanh(W1 hs^T + b1)
+    SV_MTS(0)
+    // the weight fragments' LDS-DMA first (130 KiB per workgroup: the longest latency of the head), the row loads
+    // behind it: one round trip instead of two
+    stage_frags(a.frags, OFF_F1, NFRAG_FWD, wlds, wave, lane);
+    float* bias_lds = reinterpret_cast<float*>(wlds + NFRAG_FWD * 1024);
+    if (threadIdx.x < BIAS_FLOATS / 4) {
+        const int i4 = threadIdx.x * 4;
+        const float* src = i4 < BOFF_L ? a.b1 + i4 : (i4 < BOFF_2 ? a.bl + (i4 - BOFF_L) : a.b2 + (i4 - BOFF_2));
+        *reinterpret_cast<float4*>(bias_lds + i4) = *reinterpret_cast<const float4*>(src);
+    }
+    SV_MTS(1)
     B3 hb[KS_H];
 #pragma unroll
     for (int s = 0; s < KS_H; ++s) hb[s] = row_frag<SPLIT>(a.hs + rc * SV_HP + 16 * s + 8 * lh);
-    stage_frags(a.frags, OFF_F1, NFRAG_FWD, wlds, wave, lane);
+    // the noise of this lane's row, needed two layers down: fetched here, ahead of every store
+    float4 epsv[NT_L][4];
+#pragma unroll
+    for (int q = 0; q < NT_L; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            epsv[q][g] = *reinterpret_cast<const float4*>(a.eps + rc * SV_L + 32 * q + 8 * g + 4 * lh);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SV_MTS(2)
     __syncthreads();
+    SV_MTS(3)
     B3 pe[KS_D];
 #pragma unroll
     for (int nt = 0; nt < NT_D; ++nt) {
         f32x16 c;
-        bias_init(c, a.b1, nt, lh);
+        bias_init(c, bias_lds + BOFF_1, nt, lh);
 #pragma unroll
         for (int s = 0; s < KS_H; ++s)
             mm<SPLIT>(c, wlds, OFF_F1 + nt * KS_H + s, a.frags, OFF_F1 + nt * KS_H + s, lane, hb[s]);
@@ -256,11 +300,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
         tile_store(a.enc + rc * SV_DP, nt, lh, c, ok);
         to_frags<SPLIT>(c, pe[2 * nt], pe[2 * nt + 1]);
     }
+    SV_MTS(4)
     // ---- (mu | ls)^T = Wl enc^T + bl
     f32x16 t[NT_L2];
 #pragma unroll
     for (int nt = 0; nt < NT_L2; ++nt) {
-        bias_init(t[nt], a.bl, nt, lh);
+        bias_init(t[nt], bias_lds + BOFF_L, nt, lh);
 #pragma unroll
         for (int s = 0; s < KS_D; ++s)
             mm<SPLIT>(t[nt], wlds, OFF_F2 + nt * KS_D + s, a.frags, OFF_F2 + nt * KS_D + s, lane, pe[s]);
@@ -275,7 +320,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
         f32x16 zt;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 e = *reinterpret_cast<const float4*>(a.eps + rc * SV_L + 32 * q + 8 * g + 4 * lh);
+            const float4 e = epsv[q][g];
             const float ev[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -290,11 +335,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
     kl += __shfl_xor(kl, 32, 64);
     if (ok && lh == 0) a.kl_row[r] = kl;
+    SV_MTS(5)
     // ---- decoder hidden: d1^T = tanh(W2 z^T + b2)
 #pragma unroll
     for (int nt = 0; nt < NT_D; ++nt) {
         f32x16 c;
-        bias_init(c, a.b2, nt, lh);
+        bias_init(c, bias_lds + BOFF_2, nt, lh);
 #pragma unroll
         for (int s = 0; s < KS_L; ++s)
             mm<SPLIT>(c, wlds, OFF_F3 + nt * KS_L + s, a.frags, OFF_F3 + nt * KS_L + s, lane, pz[s]);
@@ -324,6 +370,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
             }
         }
     }
+    SV_MTS(6)
+#ifdef SV_MLP_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SV_MTS(7)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_mlp_dbg[i] = ts_[i];
+#endif
 }
 
 struct MlpBwdArgs {
@@ -351,10 +404,26 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
     const size_t rc = ok ? r : a.R - 1;
 
     // ---- dz^T = W2^T dd1^T
+    // (the fragments' LDS-DMA first, then every global load of the kernel, all before its first store: see MLP_FWD_LDS)
+    stage_frags(a.frags, OFF_B1, NFRAG_BWD, wlds, wave, lane);
     B3 db[KS_D];
 #pragma unroll
     for (int s = 0; s < KS_D; ++s) db[s] = row_frag<SPLIT>(a.dd1 + rc * SV_DP + 16 * s + 8 * lh);
-    stage_frags(a.frags, OFF_B1, NFRAG_BWD, wlds, wave, lane);
+    const float kw = a.anneal * a.w_kl[rc];
+    float4 epsv[NT_L][4], muv[NT_L][4], lsv[NT_L][4], encv[NT_D][4];
+#pragma unroll
+    for (int q = 0; q < NT_L; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            epsv[q][g] = *reinterpret_cast<const float4*>(a.eps + rc * SV_L + 32 * q + 8 * g + 4 * lh);
+            muv[q][g] = *reinterpret_cast<const float4*>(a.tmp + rc * SV_L2 + 32 * q + 8 * g + 4 * lh);
+            lsv[q][g] = *reinterpret_cast<const float4*>(a.tmp + rc * SV_L2 + SV_L + 32 * q + 8 * g + 4 * lh);
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT_D; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            encv[nt][g] = *reinterpret_cast<const float4*>(a.enc + rc * SV_DP + 32 * nt + 8 * g + 4 * lh);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x16 dz[NT_L];
@@ -367,16 +436,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
             mm<SPLIT>(dz[nt], wlds, nt * KS_D + s, a.frags, OFF_B1 + nt * KS_D + s, lane, db[s]);
     }
     // ---- latent backward: dmu = dz + a w mu ;  dls = dz exp(ls) eps + a w 0.5 (exp(ls) - 1)
-    const float kw = a.anneal * a.w_kl[rc];
     B3 pd[KS_L2];
 #pragma unroll
     for (int q = 0; q < NT_L; ++q) {
         f32x16 dmu, dls;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 e = *reinterpret_cast<const float4*>(a.eps + rc * SV_L + 32 * q + 8 * g + 4 * lh);
-            const float4 m = *reinterpret_cast<const float4*>(a.tmp + rc * SV_L2 + 32 * q + 8 * g + 4 * lh);
-            const float4 l = *reinterpret_cast<const float4*>(a.tmp + rc * SV_L2 + SV_L + 32 * q + 8 * g + 4 * lh);
+            const float4 e = epsv[q][g], m = muv[q][g], l = lsv[q][g];
             const float ev[4] = {e.x, e.y, e.z, e.w}, mv[4] = {m.x, m.y, m.z, m.w}, lv[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -403,7 +469,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
             mm<SPLIT>(c, wlds, OFF_B2 - OFF_B1 + nt * KS_L2 + s, a.frags, OFF_B2 + nt * KS_L2 + s, lane, pd[s]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 y = *reinterpret_cast<const float4*>(a.enc + rc * SV_DP + 32 * nt + 8 * g + 4 * lh);
+            const float4 y = encv[nt][g];
             c[4 * g + 0] *= 1.0f - y.x * y.x; c[4 * g + 1] *= 1.0f - y.y * y.y;
             c[4 * g + 2] *= 1.0f - y.z * y.z; c[4 * g + 3] *= 1.0f - y.w * y.w;
         }
@@ -464,22 +530,22 @@ extern "C" int svae_mlp_fwd_prec(const float* hs, const float* eps, const void* 
         MlpFwdArgs a2{hs, eps, (const unsigned short*)frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R, nullptr, nullptr, nullptr, 0, 0, 0};
         static bool attr2_done = false;
         if (!attr2_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_FWD * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_FWD_LDS);
             if (e != hipSuccess) return svae_fail((int)e, "svae_mlp_fwd: LDS attribute: %s", hipGetErrorString(e));
             attr2_done = true;
         }
-        hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_FWD * 1024, (hipStream_t)stream, a2);
+        hipLaunchKernelGGL((mlp_fwd_kernel<false, true>), dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), MLP_FWD_LDS, (hipStream_t)stream, a2);
         SV_LAUNCH_CHECK();
         return 0;
     }
     MlpFwdArgs a{hs, eps, (const unsigned short*)frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R, nullptr, nullptr, nullptr, 0, 0, 0};
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_FWD * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_FWD_LDS);
         if (e != hipSuccess) return svae_fail((int)e, "svae_mlp_fwd: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_FWD * 1024, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3((R + MLP_ROWS - 1) / MLP_ROWS), dim3(256), MLP_FWD_LDS, (hipStream_t)stream, a);
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -500,11 +566,11 @@ extern "C" int svae_mlp_fwd_prep(const float* hs, const float* eps, const void* 
                  (unsigned short*)h2s, (unsigned short*)h2tb, row0, row1, R_pad};
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NFRAG_FWD * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_FWD_LDS);
         if (e != hipSuccess) return svae_fail((int)e, "svae_mlp_fwd_prep: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3((row1 - row0 + MLP_ROWS - 1) / MLP_ROWS), dim3(256), NFRAG_FWD * 1024,
+    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3((row1 - row0 + MLP_ROWS - 1) / MLP_ROWS), dim3(256), MLP_FWD_LDS,
                        (hipStream_t)stream, a);
     SV_LAUNCH_CHECK();
     return 0;
@@ -541,3 +607,9 @@ extern "C" int svae_mlp_bwd_prec(const float* dd1, const float* tmp, const float
     SV_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef SV_MLP_TIMING
+extern "C" int svae_debug_mlp(unsigned long long* out8) {
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mlp_dbg), 8 * sizeof(unsigned long long));
+}
+#endif

@@ -141,6 +141,8 @@ class SVAEEngine:
         self.gru_wgrad_side = os.environ.get("SVAE_GRU_WGRAD_SIDE", "1") == "1"
         self.gi_split = os.environ.get("SVAE_GI_SPLIT", "1") == "1"
         self.bptt_split = os.environ.get("SVAE_BPTT_SPLIT", "0") == "1"
+        self.early_embed_opt = os.environ.get("SVAE_EARLY_EMBED_OPT", "0") == "1"
+        self._early_opt = None         # train_step -> backward: (range, gscale, step number) of the embedding bucket
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.event_pool = []
         self.timer_pool = []
@@ -923,6 +925,14 @@ class SVAEEngine:
             bptt_done = torch.cuda.Event()
             bptt_done.record(cur)
             embedding_grad()
+            if self._early_opt is not None:
+                # train_step, one process: the optimizer over the embedding table (60 % of the parameters, 26 us of
+                # HBM traffic) here, under the side stream's GRU weight gradients, instead of behind the join with
+                # them -- the side stream is the longer of the two by then (tools/skip_sensitivity.sh: the GRU weight
+                # gradients hold 56 us of the step, dL/demb + scatter-add 14)
+                (s_, e_), gscale_, count_ = self._early_opt
+                self._adam_range(s_, e_, gscale_, st, count=count_)
+                self._early_opt = False          # (done: train_step leaves this bucket out)
             side.wait_event(bptt_done)
             with _Launch(side, self._torch_ctx()):
                 gru_wgrads()          # (one of the two here and one on the caller's stream: no better, 0.922 vs 0.918)
@@ -1059,34 +1069,48 @@ class SVAEEngine:
         else:
             self._opt = (self.OPTIMIZERS[kind], float(decay), float(eps))
 
-    def _adam_range(self, s, e, gscale, st):
-        """The optimizer over elements [s, e) of the flat buffers (Adam unless set_optimizer chose another)."""
+    def _adam_range(self, s, e, gscale, st, count=None):
+        """The optimizer over elements [s, e) of the flat buffers (Adam unless set_optimizer chose another); count =
+        the optimizer step's number (default: step_count, which the caller has advanced)."""
+        count = self.step_count if count is None else count
         if self._opt is not None:
             kind, decay, eps = self._opt
             _lib.call("svae_optimizer_step", kind, self.params.data_ptr() + 4 * s, self.grads.data_ptr() + 4 * s,
-                      self.exp_avg_sq.data_ptr() + 4 * s, self.exp_avg.data_ptr() + 4 * s, e - s, self.step_count,
+                      self.exp_avg_sq.data_ptr() + 4 * s, self.exp_avg.data_ptr() + 4 * s, e - s, count,
                       self.lr, decay, eps, self.weight_decay, float(gscale), st)
             return
         _lib.call("svae_adam_step", self.params.data_ptr() + 4 * s, self.grads.data_ptr() + 4 * s,
-                  self.exp_avg.data_ptr() + 4 * s, self.exp_avg_sq.data_ptr() + 4 * s, e - s, self.step_count, self.lr,
+                  self.exp_avg.data_ptr() + 4 * s, self.exp_avg_sq.data_ptr() + 4 * s, e - s, count, self.lr,
                   self.betas[0], self.betas[1], self.adam_eps, self.weight_decay, float(gscale), st)
 
     def train_step(self, plan, anneal, eps=None, seed=0, step=None):
         """forward + backward + Adam for one batch.  Returns the device tensor holding
         [loss, likelihood, KL]; reading it synchronises, so do that only when logging."""
         self._in_step = True
+        gs = self.grad_sync
+        gscale = gs.gscale if gs is not None else 1.0
+        emb_bucket = self.layout.buckets()[2]
+        # one process: backward() runs the optimizer over the embedding bucket as soon as that gradient is complete
+        self._early_opt = ((emb_bucket, gscale, self.step_count + 1)
+                           if gs is None and self.early_embed_opt and self.float_w3 else None)
         try:
             self.forward(plan, anneal, eps=eps, seed=seed, step=self.step_count if step is None else step,
                          defer_loss=True)
             self.backward()
         finally:
             self._in_step = False
-        gs = self.grad_sync
-        gscale = gs.gscale if gs is not None else 1.0
+        early_done = self._early_opt is False
+        self._early_opt = None
         if not self._float_pending:
             if gs is not None:
                 gs.wait()
-            self.adam_step(gscale)
+            if early_done:
+                self._settle()
+                self._w3_fresh = False
+                self.step_count += 1
+                self._adam_range(0, emb_bucket[0], gscale, _stream())
+            else:
+                self.adam_step(gscale)
             return self.loss_out
         # floated decoder.linear2 bucket: Adam over the other buckets here, over that one on its own stream
         self._float_pending = False
@@ -1097,8 +1121,16 @@ class SVAEEngine:
         if gs is not None:
             with _Launch(w3, True):
                 gs.bucket_ready(0)
-            gs.wait(which=[i for i in range(1, 1 + len(rest))])
-        self._adam_range(rest[0][0], rest[-1][1], gscale, cur.cuda_stream)
+            # the embedding bucket's all-reduce was issued first: its optimizer step runs under the dense + GRU
+            # bucket's collective
+            gs.wait(which=[2])
+            self._adam_range(rest[1][0], rest[1][1], gscale, cur.cuda_stream)
+            gs.wait(which=[1])
+            self._adam_range(rest[0][0], rest[0][1], gscale, cur.cuda_stream)
+        elif early_done:
+            self._adam_range(rest[0][0], rest[0][1], gscale, cur.cuda_stream)
+        else:
+            self._adam_range(rest[0][0], rest[-1][1], gscale, cur.cuda_stream)
         with _Launch(w3, gs is not None):
             if gs is not None:
                 gs.wait(which=[0])

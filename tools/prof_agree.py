@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Agreement between bench.py's kernel_ms (HIP events / dispatch timestamps in the replay pass) and the rocprofv3
 kernel trace of the SAME command:  tools/prof_agree.py <bench.json> <kernel_stats.csv> [steps_in_trace]
-Per-step milliseconds from the trace = TotalDurationNs / steps in the trace (warm-up + timed + replay)."""
+Per-step milliseconds from the trace = TotalDurationNs / steps in the trace (settle + warm-up + timed + replay)."""
 import csv
 import json
 import sys
@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(sys.argv[2])))
 # steps in the trace: warm-up + the timed region repeated ms_per_step_regions.n times + the replay pass of the kernel
 # brackets; counted from the trace itself (one optimizer launch set per step) when it holds the adam kernel
 regions = bench.get("ms_per_step_regions", {}).get("n", 1)
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else bench["warmup"] + (regions + 1) * bench["steps"]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else bench["warmup"] + (regions + 1) * bench["steps"] + bench.get("settle", {}).get("steps", 0)
 tot = {}
 for r in rows:
     tot[r["Name"]] = tot.get(r["Name"], 0.0) + float(r["TotalDurationNs"])
