@@ -231,6 +231,43 @@ def main():
     rows_bracketed = [plans[(first_step + i) % len(plans)].R for i in range(replay_steps)]
     rows_extra, kt_extra = [], {}
     eng.prof = None
+    # The sweeps ALONE: in the step they share the GPU on purpose (the forward sweep of the first time range runs on
+    # 192 CUs beside the second recurrence, the weight-gradient sweep as 158 long workgroups beside the BPTT), which
+    # is the step's optimum and not the kernel's.  One more pass over the plans with every stream folded into one, the
+    # forward in one range, the weight-gradient sweep split to fill the idle GPU in one round: the same kernels with the GPU to themselves.
+    solo = None
+    if kt and eng.fused and "proj_fdh_fused" in kt and args.prec == "bf16":
+        saved = (eng.overlap, eng.time_split, eng.dw_q, eng.fdh_q0)
+        # (weight-gradient sweep 3-way: 237 workgroups, one round on the idle GPU -- 4-way is 316, two rounds, 0.279 ms
+        # against 0.209; the forward sweep keeps its nominal 4-way split: nominal 2 leaves unequal workgroups, 0.227
+        # against 0.216)
+        eng.overlap, eng.time_split, eng.dw_q = False, False, 3
+        try:
+            for p_ in plans:
+                eng.prepare(p_)
+            n_solo = min(replay_steps, len(plans))
+            for i in range(2):
+                eng.train_step(plans[(first_step + i) % len(plans)], 0.01, seed=1234)
+            torch.cuda.synchronize()
+            eng.prof = {"proj_fdh_fused": [], "proj_dw_fused": []}
+            for i in range(n_solo):
+                eng.train_step(plans[(first_step + i) % len(plans)], 0.01, seed=1234)
+            torch.cuda.synchronize()
+            ks = harvest(n_solo)
+            rows_solo = float(np.mean([plans[(first_step + i) % len(plans)].R for i in range(n_solo)]))
+            if "proj_fdh_fused" in ks and "proj_dw_fused" in ks:
+                ms_s = ks["proj_fdh_fused"] + ks["proj_dw_fused"]
+                fl = 300.0 * I * rows_solo
+                solo = dict(avg_ms=ms_s, fdh_ms=ks["proj_fdh_fused"], dw_ms=ks["proj_dw_fused"],
+                            achieved=3 * fl / (ms_s * 1e-3) / 1e12, frac=3 * fl / (ms_s * 1e-3) / 1e12 / PEAK[args.prec],
+                            executed_frac=4 * fl / (ms_s * 1e-3) / 1e12 / PEAK[args.prec], steps=n_solo,
+                            note="the two sweeps with nothing beside them (one stream, forward in one range, "
+                                 "weight-gradient sweep as one round of 237 workgroups): the kernel's own rate; `frac` above is its rate inside "
+                                 "the overlapped step")
+        finally:
+            eng.prof = None
+            eng.overlap, eng.time_split, eng.dw_q, eng.fdh_q0 = saved
+            torch.cuda.synchronize()
     kt_all = dict(kt_extra)
     kt_all.update(kt)
     rows_step = rows_done / args.steps
@@ -300,6 +337,8 @@ def main():
                         algorithmic_flop=3 * proj_flop,
                         executed=dict(achieved=exe, frac=exe / PEAK[args.prec], flop=4 * proj_flop,
                                       note="incl. the logit recompute of the weight-gradient sweep"))
+        if solo is not None:
+            roofline["alone"] = solo
     elif rooflines:
         roofline = rooflines[max(rooflines, key=lambda k: rooflines[k]["avg_ms"])]
 

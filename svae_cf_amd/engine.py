@@ -141,6 +141,8 @@ class SVAEEngine:
         self.gru_wgrad_side = os.environ.get("SVAE_GRU_WGRAD_SIDE", "1") == "1"
         self.gi_split = os.environ.get("SVAE_GI_SPLIT", "1") == "1"
         self.bptt_split = os.environ.get("SVAE_BPTT_SPLIT", "0") == "1"
+        self.fdh_q0 = int(os.environ.get("SVAE_FDH_Q0", "4"))  # nominal split count of the forward sweep (_proj_sched)
+        self.dw_q = int(os.environ.get("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
         self.early_embed_opt = os.environ.get("SVAE_EARLY_EMBED_OPT", "0") == "1"
         self._early_opt = None         # train_step -> backward: (range, gscale, step number) of the embedding bucket
         self.grad_sync = None          # dist.GradSync for data parallel runs
@@ -616,7 +618,7 @@ class SVAEEngine:
         streamed (forward / dL/dh sweep; nx = the number of rows when only a range of the plan is swept), 'items' =
         the weight-gradient sweep.  Built once per plan and engine."""
         ncu = self._ncu if ncu is None else max(8, int(ncu))
-        key = (side, self.I, ncu, nx)
+        key = (side, self.I, ncu, nx, self.dw_q if side == "items" else self.fdh_q0)
         cache = plan.proj_sched
         if host_only:
             if key in cache:
@@ -627,7 +629,7 @@ class SVAEEngine:
                 # workgroups than the 8-way nominal write and re-read fewer slabs -- measured 3: 243.8k, 4: 245.0k,
                 # 5: 243.2k, 6: 242.0k, 8: 240.1k seq/s
                 tab, q, rem = _lib.proj_schedule(plan.R if nx is None else nx, self.I, ncu,
-                                                 uniform=-int(os.environ.get("SVAE_FDH_Q0", "4")))
+                                                 uniform=-self.fdh_q0)
             else:
                 # uniform 2-way split.  With the sweep on its own stream past the end of the step, fewer and longer
                 # workgroups win (slab traffic, and CUs left to the kernels beside it).  Round 1: 2: 249.4k, 3: 248.9k,
@@ -635,7 +637,7 @@ class SVAEEngine:
                 # Round 2, pipelined kernel (median ms per step over repeated regions): 1: 1.003, 2: 0.934, 3: 0.946,
                 # 4: 0.945, 5: 0.959, 6: 0.949, 8: 0.967 -- at 2 the 158 workgroups leave 98 CUs to the BPTT and the
                 # weight-gradient GEMMs (0.36 -> 0.27 ms) and write half the slabs of the 4-way split.
-                fq = int(os.environ.get("SVAE_DW_Q", "2"))
+                fq = self.dw_q
                 tab, q, rem = _lib.proj_schedule(self.I, plan.R, ncu, uniform=1 + fq)   # (ncu unused: uniform)
             if host_only:
                 return key, tab, q, rem
