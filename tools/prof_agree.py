@@ -11,7 +11,8 @@ rows = list(csv.DictReader(open(sys.argv[2])))
 # steps in the trace: warm-up + the timed region repeated ms_per_step_regions.n times + the replay pass of the kernel
 # brackets; counted from the trace itself (one optimizer launch set per step) when it holds the adam kernel
 regions = bench.get("ms_per_step_regions", {}).get("n", 1)
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else bench["warmup"] + (regions + 1) * bench["steps"] + bench.get("settle", {}).get("steps", 0)
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else bench["warmup"] + (regions + 1) * bench["steps"] + bench.get("settle", {}).get("steps", 0) + \
+    ((bench.get("roofline") or {}).get("alone", {}).get("steps", -2) + 2)     # the sweeps-alone pass and its 2 warm-up steps
 tot = {}
 for r in rows:
     tot[r["Name"]] = tot.get(r["Name"], 0.0) + float(r["TotalDurationNs"])
