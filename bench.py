@@ -62,8 +62,8 @@ def main():
     ap.add_argument("--items", type=int, default=None, help="catalogue size (default: the shape's)")
     ap.add_argument("--nplans", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--settle-ms", type=float, default=50.0,
-                    help="untimed steps for this many ms before the warm-up steps (an idle GPU ramps up; 0 = none)")
+    ap.add_argument("--settle-steps", type=int, default=48,
+                    help="untimed steps before the warm-up steps (an idle GPU ramps up for ~40 ms; 0 = none)")
     ap.add_argument("--sparse-embed", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: exchange the item-embedding gradient as (row id, row) pairs (auto: when fewer bytes)")
     ap.add_argument("--eval-leg", action="store_true", help="also time the scoring leg (forward + masked top-100)")
@@ -147,16 +147,16 @@ def main():
     # Device settle phase (disclosed in the JSON line as "settle"): an idle GPU needs ~40 ms of load before it runs at its
     # steady rate -- with the driver's --warmup 5 the first timed region measured 0.970 ms per step, with --warmup 16
     # 0.937, with --warmup 40 0.902, the later regions of all three 0.907-0.915 (one box, one call).  The workload's
-    # metric is sustained training throughput, so untimed steps over the same plans run for --settle-ms first; the W
+    # metric is sustained training throughput, so --settle-steps untimed steps over the same plans run first; the W
     # warm-up steps and the K timed steps then follow exactly as asked, on the same plans as without it.
-    settle_steps = 0
-    if args.settle_ms > 0:
-        t_s = time.perf_counter()
-        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
-            for p_ in plans:
-                eng.train_step(p_, 0.01, seed=1234)
-                settle_steps += 1
-            torch.cuda.synchronize()
+    # A COUNT of steps, the same on every rank (each step issues the data-parallel collectives: a time-based loop
+    # would leave the ranks with different numbers of them).
+    settle_steps = max(0, int(args.settle_steps))
+    t_s = time.perf_counter()
+    for i in range(settle_steps):
+        eng.train_step(plans[i % len(plans)], 0.01, seed=1234)
+    torch.cuda.synchronize()
+    settle_ms = (time.perf_counter() - t_s) * 1e3
     step = 0
     for i in range(args.warmup):
         eng.train_step(plans[step % len(plans)], 0.01, seed=1234)
@@ -236,7 +236,7 @@ def main():
     # is the step's optimum and not the kernel's.  One more pass over the plans with every stream folded into one, the
     # forward in one range, the weight-gradient sweep split to fill the idle GPU in one round: the same kernels with the GPU to themselves.
     solo = None
-    if kt and eng.fused and "proj_fdh_fused" in kt and args.prec == "bf16":
+    if kt and eng.fused and "proj_fdh_fused" in kt and args.prec == "bf16" and world == 1 and not rehearse:
         saved = (eng.overlap, eng.time_split, eng.dw_q, eng.fdh_q0)
         # (weight-gradient sweep 3-way: 237 workgroups, one round on the idle GPU -- 4-way is 316, two rounds, 0.279 ms
         # against 0.209; the forward sweep keeps its nominal 4-way split: nominal 2 leaves unequal workgroups, 0.227
@@ -387,7 +387,7 @@ def main():
             "metric": "train sequences/sec (%s shape)" % shape_name, "value": total_users / dt, "unit": "sequences/s",
             "n_gpus": world, "ranks_in_process_group": (dist.get_world_size() if (world > 1 or rehearse) else 1),
             "steps": args.steps, "warmup": args.warmup,
-            "settle": {"ms": args.settle_ms, "steps": settle_steps,
+            "settle": {"steps": settle_steps, "ms": settle_ms,
                        "note": "untimed steps before the warm-up: an idle GPU needs ~40 ms of load to reach its steady rate"},
             "ms_per_step": dt / args.steps * 1e3, "ms_per_step_by_rank": [d / args.steps * 1e3 for d in dt_ranks],
             "ms_per_step_regions": dict(n=len(region_ms), min=float(np.min(region_ms)),
