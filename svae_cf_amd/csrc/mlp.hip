@@ -160,7 +160,8 @@ constexpr int MLP_ROWS = 128;                  // rows per block (4 waves x 32)
 // instructions for 32 rows, one wave per SIMD.  Tried on top, no gain, not kept: the tiles stored as whole
 // 128-byte row segments through an LDS transpose (a direct store touches 32 rows per instruction; 18.6 us), and the
 // fragments of a k-loop read one tile ahead instead of ds_read -> wait -> MFMA per k-step (18.5 us).  Halving the
-// rows per SIMD (64-row workgroups) is what would shorten it; the backward's 21.8k rows then need two rounds.
+// rows per wave (16-row waves on 16x16x32 tiles, 64-row workgroups) is what would shorten it; the backward's 21.8k
+// rows then need two rounds of workgroups.
 constexpr int BIAS_FLOATS = SV_DP + SV_L2 + SV_DP;
 constexpr int MLP_FWD_LDS = NFRAG_FWD * 1024 + BIAS_FLOATS * 4;
 constexpr int BOFF_1 = 0, BOFF_L = SV_DP, BOFF_2 = SV_DP + SV_L2;
