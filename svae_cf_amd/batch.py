@@ -73,7 +73,9 @@ def choose_time_split(row_off, us_per_step=2.4, us_launch=15.0, us_chain=40.0, u
     is rounded down to a multiple of 64 rows (the rows in between ride with the second range).
     Cost model (measured on MI355X, ML-20M shape): a recurrence launch = 15 us + 2.4 us per step; the decoder side
     of r rows = 40 us + 11 us per 1000 rows, 1/0.75 of that while the recurrence holds a quarter of the CUs.
-    (Round 2, faster sweeps: the constants re-checked by moving each 20-30 % either way -- every variant 0.5-2 % slower.)
+    (Round 2, faster sweeps: the constants re-checked by moving each 20-30 % either way -- every variant 0.5-2 % slower;
+    again with the second range's MLP chain behind its recurrence on the side stream: +-25 / +50 us on the second
+    recurrence's side of the model, 0.3-1 % slower.)
     Returns (t1, r1), or (0, 0) when no cut beats the unsplit forward by 5 %."""
     row_off = np.asarray(row_off, dtype=np.int64)
     Tmax, R = len(row_off) - 1, int(row_off[-1])

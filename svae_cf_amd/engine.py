@@ -143,6 +143,7 @@ class SVAEEngine:
         self.bptt_split = os.environ.get("SVAE_BPTT_SPLIT", "0") == "1"
         self.fdh_q0 = int(os.environ.get("SVAE_FDH_Q0", "4"))  # nominal split count of the forward sweep (_proj_sched)
         self.dw_q = int(os.environ.get("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
+        self.mlp2_side = os.environ.get("SVAE_MLP2_SIDE", "1") == "1"
         self.early_embed_opt = os.environ.get("SVAE_EARLY_EMBED_OPT", "0") == "1"
         self._early_opt = None         # train_step -> backward: (range, gscale, step number) of the embedding bucket
         self.grad_sync = None          # dist.GradSync for data parallel runs
@@ -467,6 +468,13 @@ class SVAEEngine:
                 if t1 > 0:
                     side.wait_event(first_done)
                     gru_range(t1, plan.Tmax, "gru_fwd2")
+                    if self.mlp2_side and self._w3_event is not None:
+                        # the MLP chain of the second range's rows here, behind their recurrence, on the CUs it has
+                        # just freed: the caller's stream is still in the first range's sweep (the floated
+                        # decoder.linear2 work of the step before read d1 / h2b, which this overwrites)
+                        side.wait_event(self._w3_event)
+                    if self.mlp2_side:
+                        self._decoder_rows(plan, r1, R, self._ncu, sweep=False)
                     second_done = torch.cuda.Event()
                     second_done.record(side)
         if eps is not None:
@@ -492,7 +500,7 @@ class SVAEEngine:
                 self._last_fused = True
                 self._decoder_rows(plan, 0, r1, self._ncu - (plan.B + 3) // 4)
                 cur.wait_event(second_done)
-                self._decoder_rows(plan, r1, R, self._ncu)
+                self._decoder_rows(plan, r1, R, self._ncu, mlp=not self.mlp2_side)
                 self._fused_grad = True
                 if defer_loss and self.overlap:
                     self._loss_deferred = True
@@ -562,13 +570,15 @@ class SVAEEngine:
                   w["d1"].data_ptr() + 4 * DP * r0, w["kl_row"].data_ptr() + 4 * r0, n, self.prec, _stream())
         self._toc("mlp_fwd", ev)
 
-    def _decoder_rows(self, plan, r0, r1, ncu):
-        """Decoder side of rows [r0, r1) of the plan (r0 a multiple of 64): MLP chain, bf16 operand copies, forward
-        + dL/dh sweep of the projection and its finish.  Every array is row-major, so a row range is a pointer
-        offset; the slab scratch of a range starts where the previous range's ends."""
+    def _decoder_rows(self, plan, r0, r1, ncu, mlp=True, sweep=True):
+        """Decoder side of rows [r0, r1) of the plan (r0 a multiple of 64): MLP chain, bf16 operand copies (mlp),
+        forward + dL/dh sweep of the projection and its finish (sweep).  Every array is row-major, so a row range is
+        a pointer offset; the slab scratch of a range starts where the previous range's ends."""
         w, R, n = self.ws, plan.R, r1 - r0
         Rp = (R + 63) // 64 * 64
-        if self.fused_prep:
+        if not mlp:
+            pass
+        elif self.fused_prep:
             # MLP chain and the sweeps' operand copies in one kernel (svae_mlp_fwd_prep)
             ev = self._tic("mlp_fwd")
             _lib.call("svae_mlp_fwd_prep", w["hs"].data_ptr(), w["eps"].data_ptr(), self.mlp_frags.data_ptr(),
@@ -581,6 +591,8 @@ class SVAEEngine:
             self._mlp_fwd_rows(r0, r1)
             _lib.call("svae_proj_prep_rows_range", w["d1"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
                       w["h2b"].data_ptr(), w["h2s"].data_ptr(), _lib.ptr(w["h2tb"]), _stream())
+        if not sweep:
+            return
         nsm = _lib.load().svae_proj_ns_max()
         args = (w["h2s"].data_ptr() + 2 * DP * r0, w["h2b"].data_ptr() + 2 * DP * r0, self.w3b.data_ptr(),
                 _lib.ptr(self.w3tb), self.IPAD, w["d1"].data_ptr() + 4 * DP * r0,
