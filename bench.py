@@ -66,6 +66,8 @@ def main():
                     help="untimed steps before the warm-up steps (an idle GPU ramps up for ~40 ms; 0 = none)")
     ap.add_argument("--sparse-embed", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: exchange the item-embedding gradient as (row id, row) pairs (auto: when fewer bytes)")
+    ap.add_argument("--shard-w3", default="auto", choices=["auto", "on", "off"],
+                    help="decoder.linear2 gradient: reduce-scatter + sharded optimizer + all-gather (auto: >= 100k items)")
     ap.add_argument("--eval-leg", action="store_true", help="also time the scoring leg (forward + masked top-100)")
     ap.add_argument("--no-kernel-times", action="store_true", help="do not bracket kernels with events (no roofline)")
     ap.add_argument("--repeats", type=int, default=5,
@@ -137,6 +139,10 @@ def main():
         if args.sparse_embed == "on" or (args.sparse_embed == "auto" and GradSync.sparse_rows_pay(I, cap_rows, world)):
             from svae_cf_amd.layout import E as _E
             eng.grad_sync.enable_sparse_rows(2, I, _E, capacity=cap_rows)
+        # ... and the decoder.linear2 bucket (151 I floats, dense by nature) as reduce-scatter + sharded optimizer step
+        # + all-gather: the same bytes on the links, the optimizer's 28 B per parameter once per job, not per rank
+        if args.shard_w3 == "on" or (args.shard_w3 == "auto" and world > 1 and I >= 100000):
+            eng.grad_sync.enable_sharded(0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -398,6 +404,7 @@ def main():
                                    "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam"
                                    % (shape_name, shape_cfg, I, lmax, B),
                        "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "mean_rows_bracketed_steps": rows_timed, "parallelism": "dp%d" % world, "embedding_gradient_exchange": ("rows" if (eng.grad_sync is not None and eng.grad_sync.sparse is not None) else "dense"),
+                       "decoder_linear2_exchange": ("reduce-scatter + sharded optimizer + all-gather" if (eng.grad_sync is not None and eng.grad_sync.sharded is not None) else "all-reduce"),
                        "final_loss": loss, "side_stream": eng.side_stream_info},
             "kernel_ms": kt, "kernel_timing": "HIP events on the launch streams over a replay of the first %d timed steps "
                                              "(events inside the timed region stall the launch pipeline)" % replay_steps, "roofline": roofline, "rooflines": rooflines,

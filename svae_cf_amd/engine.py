@@ -1115,10 +1115,22 @@ class SVAEEngine:
             self._in_step = False
         early_done = self._early_opt is False
         self._early_opt = None
+        sharded = gs is not None and gs.active and gs.sharded is not None and gs.sharded["bucket"] == 0
         if not self._float_pending:
             if gs is not None:
                 gs.wait()
-            if early_done:
+            if sharded:
+                # decoder.linear2 bucket: the optimizer over this rank's shard only, the parameters all-gathered
+                self._settle()
+                self._w3_fresh = False
+                self.step_count += 1
+                (s0, e0), a_b = self.layout.buckets()[0], gs.shard_range()
+                self._adam_range(a_b[0], a_b[1], gscale, _stream())
+                self._adam_range(e0, self.layout.total, gscale, _stream())
+                wk = gs.gather_params(self.params)
+                if wk is not None:
+                    wk.wait()
+            elif early_done:
                 self._settle()
                 self._w3_fresh = False
                 self.step_count += 1
@@ -1148,7 +1160,14 @@ class SVAEEngine:
         with _Launch(w3, gs is not None):
             if gs is not None:
                 gs.wait(which=[0])
-            self._adam_range(s0, e0, gscale, _stream())
+            if sharded:
+                a_, b_ = gs.shard_range()
+                self._adam_range(a_, b_, gscale, _stream())
+                wk = gs.gather_params(self.params)
+                if wk is not None:
+                    wk.wait()
+            else:
+                self._adam_range(s0, e0, gscale, _stream())
             self._proj_prep_items(_stream())
         self._w3_event = torch.cuda.Event()
         self._w3_event.record(w3)

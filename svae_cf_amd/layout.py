@@ -56,6 +56,11 @@ class ParamLayout:
                 assert off == prev.offset + prev.size, name
             self.entries[name] = Entry(name, off, g, r, c, pr, pc, size)
             off = _round_up(off + size, 64)     # every tensor starts 256-byte aligned
+            if name == "decoder.linear2.bias":
+                # bucket 0 (decoder.linear2.*) ends on a multiple of 512 floats: it splits into 1, 2, 4 or 8 equal
+                # shards of whole 256-byte lines (dist.GradSync.enable_sharded: reduce-scatter, sharded optimizer
+                # step, all-gather).  The pad floats are zero and stay zero like every other pad.
+                off = _round_up(off, 512)
         self.total = off
         # reference shapes at the boundary
         self.ref_shapes = {
@@ -111,8 +116,11 @@ class ParamLayout:
         names = list(self.entries.keys())
         groups = [names[0:2], names[2:12], names[12:13]]
         out = []
-        for gnames in groups:
+        for gi, gnames in enumerate(groups):
             s = self.entries[gnames[0]].offset
             last = self.entries[gnames[-1]]
-            out.append((s, _round_up(last.offset + last.size, 64)))
+            end = _round_up(last.offset + last.size, 64)
+            if gi == 0:
+                end = self.entries[groups[1][0]].offset        # incl. the pad up to a multiple of 512 floats
+            out.append((s, end))
         return out

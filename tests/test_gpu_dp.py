@@ -31,7 +31,7 @@ def _init_sd(layout):
     return {n: torch.randn(s, generator=g) * 0.1 for n, s in layout.ref_shapes.items()}
 
 
-def _run(rank, world, prec, port, q, opt="adam", sparse=False):
+def _run(rank, world, prec, port, q, opt="adam", sparse=False, shard=False):
     sys.path.insert(0, ROOT)
     if q is not None:
         # a rank that stops making progress dumps its stacks and exits instead of hanging the test run
@@ -59,6 +59,8 @@ def _run(rank, world, prec, port, q, opt="adam", sparse=False):
         if sparse:      # the item-embedding gradient as (row id, row) pairs: the large-catalogue exchange
             from svae_cf_amd.layout import E
             eng.grad_sync.enable_sparse_rows(2, I, E, capacity=max(len(u) for u in users) * B)
+        if shard:       # decoder.linear2: reduce-scatter, optimizer over the rank's shard, parameters all-gathered
+            eng.grad_sync.enable_sharded(0)
     losses = []
     for s in range(STEPS):
         idx = mine[s] if world > 1 else np.concatenate(steps[s])
@@ -86,15 +88,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("prec,opt,sparse", [(0, "adam", False), (1, "adam", False), (0, "adagrad", False),
-                                             (0, "adam", True)])
-def test_two_ranks_equal_union_batch(prec, opt, sparse):
+@pytest.mark.parametrize("prec,opt,sparse,shard", [(0, "adam", False, False), (1, "adam", False, False),
+                                                   (0, "adagrad", False, False), (0, "adam", True, False),
+                                                   (1, "adam", False, True), (0, "adagrad", True, True)])
+def test_two_ranks_equal_union_batch(prec, opt, sparse, shard):
     import torch.multiprocessing as mp
     ref_sd, ref_losses = _run(0, 1, prec, 0, None, opt)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_run, args=(r, WORLD, prec, port, q, opt, sparse), daemon=True) for r in range(WORLD)]
+    ps = [ctx.Process(target=_run, args=(r, WORLD, prec, port, q, opt, sparse, shard), daemon=True) for r in range(WORLD)]
     for p in ps:
         p.start()
     try:

@@ -322,6 +322,67 @@ def test_sparse_row_exchange_equals_dense_allreduce_gloo_world2():
     assert res[0][2] > 0 and res[0][3] == res[1][3]
 
 
+def _sharded_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from svae_cf_amd.dist import GradSync
+    from svae_cf_amd.layout import ParamLayout
+    lay = ParamLayout(501)
+    (s0, e0) = lay.buckets()[0]
+    gen = torch.Generator().manual_seed(7 + rank)
+    g = torch.randn(lay.total, generator=gen)
+    want = None
+    if True:
+        # the sum every rank must see on its shard = what the dense all-reduce gives
+        ref = g.clone()
+        dist.all_reduce(ref)
+        want = ref
+    params = torch.full((lay.total,), -1.0)
+    sync = GradSync(g, lay.buckets())
+    sync.enable_sharded(0)
+    a, b = sync.shard_range()
+    for i in range(3):
+        sync.bucket_ready(i)
+    sync.wait()
+    shard_ok = torch.equal(g[a:b], want[a:b]) and torch.equal(g[e0:], want[e0:])
+    # "optimizer step" over the own shard only, then the parameters go round
+    params[a:b] = g[a:b] * 0.5
+    wk = sync.gather_params(params)
+    if wk is not None:
+        wk.wait()
+    gathered_ok = torch.equal(params[s0:e0], want[s0:e0] * 0.5) and bool((params[e0:] == -1.0).all())
+    q.put((rank, (a, b), (s0, e0), shard_ok, gathered_ok))
+    dist.destroy_process_group()
+
+
+def test_sharded_bucket_reduce_scatter_allgather_gloo_world2():
+    """GradSync.enable_sharded: the decoder.linear2 bucket (padded by ParamLayout to a multiple of 512 floats) splits
+    into `world` equal shards; after the exchange a rank's shard holds the all-reduce's sum, an update of that shard
+    alone followed by ``gather_params`` leaves every rank with the whole updated bucket and nothing beyond it
+    touched.  (gloo has no reduce-scatter: the bucket is all-reduced there, the rank's shard of it is the same sum;
+    RCCL runs the in-place reduce_scatter_tensor / all_gather_into_tensor pair.)"""
+    import torch.multiprocessing as mp
+    from svae_cf_amd.layout import ParamLayout
+    for items in (97, 501, 20000, 26744):
+        s0, e0 = ParamLayout(items).buckets()[0]
+        assert s0 == 0 and e0 % 512 == 0 and e0 >= 151 * items
+        assert ParamLayout(items).entries["decoder.linear1.weight"].offset == e0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    (s0, e0) = res[0][2]
+    assert res[0][1][0] == s0 and res[0][1][1] == res[1][1][0] and res[1][1][1] == e0      # shards tile the bucket
+    assert all(r[3] and r[4] for r in res), res
+
+
 # ---------------------------------------------------------------------------------------------
 # epoch driver's log lines against the reference's OWN printed output (SURVEY 8f row 2)
 # ---------------------------------------------------------------------------------------------
