@@ -214,6 +214,10 @@ int svae_wgrad_cols_prec(const float* dy, const float* x, float* out, float* col
                          int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, int prec,
                          void* stream);
 int svae_rowgemm_prep_prec(const float* wih, int which, void* frags, int prec, void* stream);
+/* svae_embed_fwd over rows [0, R) and svae_rowgemm_prep_prec(wih, 0, frags, 1) in ONE launch: the two independent
+ * kernels that head a training step (reference: nn.Embedding call nb:756, the GRU's input weights nb:724). */
+int svae_embed_fwd_wih_prep(const float* table, const int* x, float* out, int R, int I, const float* wih, void* frags,
+                            void* stream);
 int svae_rowgemm_ld_prec(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,
                          int prec, void* stream);
 int svae_mlp_prep_prec(const float* w1, const float* wl, const float* w2, void* frags, int prec, void* stream);

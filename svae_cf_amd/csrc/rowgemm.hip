@@ -220,6 +220,39 @@ __global__ void rowgemm_prep_kernel(const float* __restrict__ src, int sn, int s
     (void)NT;
 }
 
+// Head of a training step in ONE launch: the embedding gather of the first rows (one wave per row: 64 lanes x 16 B =
+// one 1 KiB row) and the bf16 fragments of W_ih for the input-gate GEMM that follows it (rowgemm_prep_kernel<0>'s
+// work, one wave per fragment).  They are independent of each other and both head the step's critical path: one
+// launch gap instead of two.
+constexpr int RG_PREP0_FRAGS = (SV_G / 32) * (SV_E / 16);
+__global__ __launch_bounds__(256) void embed_wih_prep_kernel(const float* __restrict__ table, const int* __restrict__ x,
+                                                             float* __restrict__ out, int R, int I,
+                                                             const float* __restrict__ wih,
+                                                             unsigned short* __restrict__ frags) {
+    constexpr int PREP_BLOCKS = RG_PREP0_FRAGS / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x < PREP_BLOCKS) {
+        using S = RgShape<0>;
+        constexpr int KS = S::K / 16;
+        const int f = blockIdx.x * 4 + wave;              // fragment id = tile * KS + ks
+        const int tile = f / KS, ks = f % KS;
+        const int li = lane & 31, lh = lane >> 5;
+        unsigned short* d = frags + rg_frag_off<0>(tile, ks) + lane * 8;
+        const int n = 32 * tile + li, k0 = 16 * ks + 8 * lh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = sv_f2bf(wih[(size_t)n * SV_E + (k0 + j)]);
+        return;
+    }
+    int row = (blockIdx.x - PREP_BLOCKS) * 4 + wave;
+    const int stride = (gridDim.x - PREP_BLOCKS) * 4;
+    for (; row < R; row += stride) {
+        const int it = x[row];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it >= 0 && it < I) v = reinterpret_cast<const float4*>(table + (size_t)it * SV_E)[lane];
+        reinterpret_cast<float4*>(out + (size_t)row * SV_E)[lane] = v;
+    }
+}
+
 template <int WHICH, bool XB, bool SPLIT = false>
 int rg_launch(RgArgs a, hipStream_t st) {
     using S = RgShape<WHICH>;
@@ -239,6 +272,20 @@ int rg_launch(RgArgs a, hipStream_t st) {
 }
 
 }  // namespace
+
+// svae_embed_fwd (rows [0, R) of the plan) and svae_rowgemm_prep_prec(wih, 0, frags, 1) in one launch (bf16 mode).
+// Reference: nn.Embedding call nb:756; the fragments are this build's operand form of gru.weight_ih_l0 (nb:724).
+extern "C" int svae_embed_fwd_wih_prep(const float* table, const int* x, float* out, int R, int I, const float* wih,
+                                       void* frags, void* stream) {
+    SV_CHECK_ARG(table && x && out && wih && frags && R > 0 && I > 0, "svae_embed_fwd_wih_prep: bad arguments");
+    static_assert(RG_PREP0_FRAGS % 4 == 0, "four fragments per workgroup");
+    int gather_blocks = (R + 3) / 4;
+    if (gather_blocks > 8192) gather_blocks = 8192;     // grid-stride beyond that
+    hipLaunchKernelGGL(embed_wih_prep_kernel, dim3(RG_PREP0_FRAGS / 4 + gather_blocks), dim3(256), 0, (hipStream_t)stream,
+                       table, x, out, R, I, wih, (unsigned short*)frags);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int svae_rowgemm_frag_elems(int which) {
     return which == 0 ? SV_G * SV_E : which == 1 ? SV_E * SV_G : -1;

@@ -143,6 +143,7 @@ class SVAEEngine:
         self.bptt_split = os.environ.get("SVAE_BPTT_SPLIT", "0") == "1"
         self.fdh_q0 = int(os.environ.get("SVAE_FDH_Q0", "4"))  # nominal split count of the forward sweep (_proj_sched)
         self.dw_q = int(os.environ.get("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
+        self.head_fused = os.environ.get("SVAE_HEAD_FUSED", "1") == "1"
         self.mlp2_side = os.environ.get("SVAE_MLP2_SIDE", "1") == "1"
         self.early_embed_opt = os.environ.get("SVAE_EARLY_EMBED_OPT", "0") == "1"
         self._early_opt = None         # train_step -> backward: (range, gscale, step number) of the embedding bucket
@@ -401,13 +402,21 @@ class SVAEEngine:
         gi_split = (plan.split_r if (self.fused and self.rowgemm and self.gi_split and self.overlap and self.time_split
                                      and want_loss and want_grad and self.gru_prec == PREC_BF16 and plan.split_t > 0)
                     else 0)
-        _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
-                  w["emb"].data_ptr(), gi_split if gi_split else R, self.I, st)
+        head_fused = self.fused and self.rowgemm and self.prec == PREC_BF16 and self.head_fused
+        if head_fused:
+            # gather + W_ih fragments in one launch (both head the step, neither needs the other)
+            _lib.call("svae_embed_fwd_wih_prep", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
+                      w["emb"].data_ptr(), gi_split if gi_split else R, self.I, self.P("gru.weight_ih_l0").data_ptr(),
+                      self.wih_frags[0].data_ptr(), st)
+        else:
+            _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
+                      w["emb"].data_ptr(), gi_split if gi_split else R, self.I, st)
         if self.fused and self.rowgemm:
             # W_ih fragments are built here, on the caller's stream (the GEMM is the second kernel of the step: the
             # side stream's preparation would not be ready in time), 2 us
-            _lib.call("svae_rowgemm_prep_prec", self.P("gru.weight_ih_l0").data_ptr(), 0, self.wih_frags[0].data_ptr(),
-                      self.prec, st)
+            if not head_fused:
+                _lib.call("svae_rowgemm_prep_prec", self.P("gru.weight_ih_l0").data_ptr(), 0,
+                          self.wih_frags[0].data_ptr(), self.prec, st)
             ev = self._tic("gi_gemm")
             _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr(), E, self.wih_frags[0].data_ptr(),
                       self.P("gru.bias_ih_l0").data_ptr(), w["gi"].data_ptr(), gi_split if gi_split else R, 0,
