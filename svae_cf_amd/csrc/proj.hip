@@ -1343,6 +1343,9 @@ extern "C" int svae_proj_prep_items(const float* w3, const float* b3, int I, int
 // a schedule (svae_proj_schedule) must cover every x tile of nx rows exactly ns_j times: cheap consistency check
 // of the three numbers the caller hands back (a stale schedule would leave slabs unwritten)
 static bool sched_ok(int nx, int nwg, int ns_q, int ns_rem) {
+#ifdef SV_EXP_SCHED_ANY
+    return true;        // timing experiments with hand-made schedules (results wrong by construction)
+#endif
     const int xt = (nx + BX - 1) / BX;
     return ns_q >= 1 && ns_q <= NS_MAX && ns_rem >= 0 && ns_rem < xt && ns_q + (ns_rem > 0) <= NS_MAX &&
            (long long)ns_q * xt + ns_rem == nwg;
