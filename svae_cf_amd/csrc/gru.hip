@@ -347,6 +347,9 @@ constexpr int WLF_ELEMS = 6 * WL_FRAGS * 64 * 8;
 constexpr int FWD_WAVES = 8;
 constexpr int XS_FLOATS = 2 * 3 * 64;              // re-deal scratch of one wave: [tile][gate][user][unit]
 
+#ifndef SV_GRU_ALT
+#define SV_GRU_ALT 1
+#endif
 template <int NQ>  // number of hidden tiles this wave owns (2 for waves 0..5; 1 for waves 6,7)
 __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned short* h_bf, unsigned short* w_lds,
                                                   float* xs, int wave, int lane) {
@@ -354,6 +357,7 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_HP / 32;  // 7 k-steps
     constexpr int NL = NQ - 1;      // tiles in LDS
+    constexpr bool ALT = SV_GRU_ALT != 0;
 
     bf16x8 W[3][KS];
 #pragma unroll
@@ -492,6 +496,13 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
 #pragma unroll
             for (int g = 0; g < 3; ++g)
                 acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s], W[g][s], acc[0][g], 0, 0, 0);
+        // Per-tile alternation (waves that own two tiles): the gate math of tile 0 is issued in slices BETWEEN the
+        // k-step groups of tile 1's MFMAs -- a wave issues in order, so vector work placed behind its last MFMA only
+        // starts when the pipe has taken all of them; in the gaps it costs nothing and the partner wave's MFMAs fill
+        // the pipe meanwhile.  sched_barrier(0) pins each slice to its gap.  Same arithmetic, same order per element.
+        float gh[NQ][3];
+        float a_er = 0.f, a_ez = 0.f, a_rg = 0.f, a_zg = 0.f, a_en = 0.f, a_ng = 0.f, a_hn = 0.f;
+#define SV_SLICE_FENCE __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NGRP; ++i) {
             SV_PIN_ORDER
@@ -499,8 +510,27 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
 #pragma unroll
             for (int g = 0; g < 3; ++g)
                 acc[NQ - 1][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], wb[i % (PD + 1)][g], acc[NQ - 1][g], 0, 0, 0);
+            if (NQ == 2 && ALT) {
+                SV_SLICE_FENCE
+                if (i == 0) gh[0][0] = redeal_rows(acc[0][0]);
+                if (i == 1) gh[0][1] = redeal_rows(acc[0][1]);
+                if (i == 2) gh[0][2] = redeal_rows(acc[0][2]);
+                if (i == 3) {
+                    a_er = __builtin_amdgcn_exp2f((gi[0][0] + gh[0][0]) * -1.4426950408889634f) + 1.0f;
+                    a_ez = __builtin_amdgcn_exp2f((gi[0][1] + gh[0][1]) * -1.4426950408889634f) + 1.0f;
+                }
+                if (i == 4) { a_rg = __builtin_amdgcn_rcpf(a_er); a_zg = __builtin_amdgcn_rcpf(a_ez); }
+                if (i == 5) a_en = __builtin_amdgcn_exp2f(__builtin_fmaf(a_rg, gh[0][2], gi[0][2]) * -2.8853900817779268f) + 1.0f;
+                if (i == 6) {
+                    a_ng = __builtin_amdgcn_rcpf(a_en) * 2.0f - 1.0f;
+                    a_hn = __builtin_fmaf(a_zg, hreg[0] - a_ng, a_ng);
+                    if (lk < MU) hnxt[lk * HLDB + 16 * wave + ln] = sv_f2bf(a_hn);
+                }
+                SV_SLICE_FENCE
+            }
         }
         SV_PIN_ORDER
+#undef SV_SLICE_FENCE
 #ifdef SV_GRU_TIMING
         asm volatile("v_mov_b32 %0, %0" : "+v"(acc[NQ - 1][2][3]));
         asm volatile("s_nop 0" ::: "memory");
@@ -509,9 +539,9 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
 #undef SV_WLOAD
 #undef SV_PIN_ORDER
         // re-deal: every lane picks its (user lk, unit ln) values out of rows 0..3 of the accumulator tiles
-        float gh[NQ][3];
+        constexpr bool DONE0 = NQ == 2 && ALT;      // tile 0 went through its gate math between tile 1's MFMAs
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int q = DONE0 ? 1 : 0; q < NQ; ++q)
 #pragma unroll
             for (int g = 0; g < 3; ++g) gh[q][g] = redeal_rows(acc[q][g]);
 #ifdef SV_GRU_TIMING
@@ -519,8 +549,12 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
 #endif
         SV_TS(3)
         float s_hn[NQ], s_hp[NQ], s_rg[NQ], s_zg[NQ], s_ng[NQ];
+        if (DONE0) {
+            s_hn[0] = a_hn; s_hp[0] = hreg[0]; s_rg[0] = a_rg; s_zg[0] = a_zg; s_ng[0] = a_ng;
+            hreg[0] = a_hn;
+        }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+        for (int q = DONE0 ? 1 : 0; q < NQ; ++q) {
             const int j = 16 * (wave + 8 * q) + ln;
             const float er = __builtin_amdgcn_exp2f((gi[q][0] + gh[q][0]) * -1.4426950408889634f) + 1.0f;
             const float ez = __builtin_amdgcn_exp2f((gi[q][1] + gh[q][1]) * -1.4426950408889634f) + 1.0f;
