@@ -223,6 +223,39 @@ def test_fused_operand_copies_equal_the_two_kernel_path():
         assert torch.equal(got[False][k], got[True][k]), k
 
 
+def test_step_order_options_leave_the_step_bit_identical():
+    """The late scheduling moves of round 2 change where and when kernels run, not what they compute: the gather and
+    the W_ih fragments in one launch (svae_embed_fwd_wih_prep) against the two kernels, and the second time range's
+    MLP chain on the side stream against the caller's -- loss, every gradient and the parameters after the optimizer
+    step are bit-identical, over three train steps of an ML-20M-shaped batch with a time split."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    I, B = 20000, 256
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(2048, I, mu, sigma, lmax, seed=4321)
+    plan = None
+    for cand in synth.bucketed_batches([len(u) for u in users], B, np.random.default_rng(2)):
+        p = S.build_plan([users[i] for i in cand], 4, user_keys=cand, device="cuda", total_items=I)
+        if p.split_t > 0:
+            plan = p
+            break
+    assert plan is not None
+    got = {}
+    for tag, head, mlp2 in (("old", False, False), ("new", True, True)):
+        eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+        _init(eng, 5)
+        eng.head_fused, eng.mlp2_side = head, mlp2
+        eng.prepare(plan)
+        losses = []
+        for s in range(3):
+            losses.append(eng.train_step(plan, 0.05, seed=9, step=s).clone())
+        torch.cuda.synchronize()
+        got[tag] = dict(losses=torch.stack(losses), grads=eng.grads.clone(), params=eng.params.clone(),
+                        frags=eng.wih_frags[0].clone(), emb=eng.ws["emb"][:plan.R * 256].clone())
+    for k in got["old"]:
+        assert torch.equal(got["old"][k], got["new"][k]), k
+
+
 def test_two_range_bptt_equals_one_launch():
     """svae_gru_bwd_range_bf16out: the BPTT as two launches (timesteps >= tb, then < tb, the recurrent part of dL/dh
     handed over in dh_carry) against the single launch, on an ML-20M-shaped batch with a time split: the gate-gradient
