@@ -142,6 +142,7 @@ class SVAEEngine:
         self.gi_split = os.environ.get("SVAE_GI_SPLIT", "1") == "1"
         self.bptt_split = os.environ.get("SVAE_BPTT_SPLIT", "0") == "1"
         self.fdh_q0 = int(os.environ.get("SVAE_FDH_Q0", "4"))  # nominal split count of the forward sweep (_proj_sched)
+        self._sched_cache = {}         # tile-count shape -> (device table, nwg, ns_q, ns_rem), see _proj_sched
         self.dw_q = int(os.environ.get("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
         self.head_fused = os.environ.get("SVAE_HEAD_FUSED", "1") == "1"
         self.mlp2_side = os.environ.get("SVAE_MLP2_SIDE", "1") == "1"
@@ -641,6 +642,16 @@ class SVAEEngine:
         ncu = self._ncu if ncu is None else max(8, int(ncu))
         key = (side, self.I, ncu, nx, self.dw_q if side == "items" else self.fdh_q0)
         cache = plan.proj_sched
+        # A table depends on the plan only through its tile counts: x tiles of 256 rows (the forward sweep of nx
+        # rows) or y tiles of 64 rows (the weight-gradient sweep of R rows).  The engine keeps every table it has
+        # uploaded under that shape: over an epoch most plans find theirs here, and `prepare` -- which runs on the
+        # prefetcher's worker threads and holds the interpreter lock for most of its 0.15-0.25 ms -- becomes a few
+        # dictionary look-ups.  (Inserted only after its upload has been enqueued: whoever finds a table there orders
+        # its own work behind that copy -- the prefetcher's workers share one copy stream, the others use the caller's.)
+        shape = (("rows", ((plan.R if nx is None else nx) + 255) // 256, ncu, self.fdh_q0) if side == "rows"
+                 else ("items", (plan.R + 63) // 64, self.dw_q))
+        if key not in cache and shape in self._sched_cache:
+            cache[key] = self._sched_cache[shape]
         if host_only:
             if key in cache:
                 return None
@@ -661,8 +672,8 @@ class SVAEEngine:
                 fq = self.dw_q
                 tab, q, rem = _lib.proj_schedule(self.I, plan.R, ncu, uniform=1 + fq)   # (ncu unused: uniform)
             if host_only:
-                return key, tab, q, rem
-            cache[key] = (torch.from_numpy(tab).to(self.device), int(tab.shape[0]), q, rem)
+                return key, tab, q, rem, shape
+            cache[key] = self._sched_cache[shape] = (torch.from_numpy(tab).to(self.device), int(tab.shape[0]), q, rem)
         t, n, q, rem = cache[key]
         return (t.data_ptr(), n, q, rem)
 
@@ -688,11 +699,11 @@ class SVAEEngine:
             with _POOL_LOCK:
                 if self._pin_pool is None:
                     self._pin_pool = _PinnedPool()
-        n = sum(int(t.shape[0]) for _, t, _, _ in made)
+        n = sum(int(t.shape[0]) for _, t, _, _, _ in made)
         host = self._pin_pool.take(16 * n)
         hv = host[:16 * n].view(torch.int32).view(n, 4)
         o = 0
-        for _, t, _, _ in made:
+        for _, t, _, _, _ in made:
             hv[o:o + t.shape[0]] = torch.from_numpy(t)
             o += int(t.shape[0])
         dev = hv.to(self.device, non_blocking=True)
@@ -700,8 +711,8 @@ class SVAEEngine:
         ev.record()
         self._pin_pool.give(host, ev)
         o = 0
-        for key, t, q, rem in made:
-            plan.proj_sched[key] = (dev[o:o + t.shape[0]], int(t.shape[0]), q, rem)
+        for key, t, q, rem, shape in made:
+            plan.proj_sched[key] = self._sched_cache[shape] = (dev[o:o + t.shape[0]], int(t.shape[0]), q, rem)
             o += int(t.shape[0])
         return plan
 

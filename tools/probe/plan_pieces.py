@@ -30,3 +30,17 @@ for rep in range(2):
         T["total"] += time.perf_counter() - t0
     torch.cuda.synchronize()
     print({k: round(v / NB * 1e3, 3) for k, v in T.items()})
+
+# ... and engine.prepare (the sweeps' schedule tables) per plan
+eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+plans = []
+for b in range(NB):
+    idx = np.arange(B * b, B * b + B)
+    plans.append(batch.build_plan_native(csr, idx, 4, user_keys=idx, total_items=I, device=torch.device("cuda:0"), stream=cs, host_alloc=pool.take, host_release=pool.give))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+with torch.cuda.stream(cs):
+    for p in plans:
+        eng.prepare(p)
+torch.cuda.synchronize()
+print({"prepare_ms_per_plan": round((time.perf_counter() - t0) / NB * 1e3, 3)})
