@@ -250,6 +250,11 @@ int svae_proj_nll_bwd_dw_split(const void* w3s, const void* h2b, const void* h2t
  * sweep launch with start / stop events (from svae_event_create) attached to the dispatch itself; read the kernel's
  * duration with svae_event_elapsed_ms (synchronises on the stop event). */
 int svae_event_create(void** out_event);
+/* Ordering events between the step's streams (host helpers, no counterpart in the reference): an event without
+ * timing, its record on a stream, a stream's wait for it. */
+int svae_sync_event_create(void** out_event);
+int svae_event_record(void* event, void* stream);
+int svae_stream_wait_event(void* stream, void* event);
 int svae_event_destroy(void* event);
 int svae_event_elapsed_ms(void* start, void* stop, float* ms);
 int svae_proj_time_next(void* start, void* stop);

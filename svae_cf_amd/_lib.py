@@ -57,6 +57,9 @@ SIGNATURES = {
     "svae_mlp_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "svae_spin": [_I, _P],
     "svae_event_create": [_P],
+    "svae_sync_event_create": [_P],
+    "svae_event_record": [_P, _P],
+    "svae_stream_wait_event": [_P, _P],
     "svae_event_destroy": [_P],
     "svae_event_elapsed_ms": [_P, _P, _P],
     "svae_proj_time_next": [_P, _P],
@@ -176,6 +179,29 @@ def plan_fns():
 
 def last_error():
     return load().svae_last_error().decode("utf-8", "replace")
+
+
+class SyncEvent:
+    """An ordering event (no timing) recorded and waited for through the library's thin HIP wrappers; the engine keeps
+    one per purpose and re-records it every step (a wait refers to the record that precedes it in host order)."""
+    __slots__ = ("h",)
+
+    def __init__(self):
+        a = _c.c_void_p()
+        call("svae_sync_event_create", _c.byref(a))
+        self.h = a.value
+
+    def record(self, stream):
+        """stream: a torch.cuda.Stream (or anything with .cuda_stream)."""
+        call("svae_event_record", self.h, stream.cuda_stream)
+
+
+def stream_wait(stream, ev):
+    """Order `stream` behind `ev` (a SyncEvent or a torch.cuda.Event)."""
+    if type(ev) is SyncEvent:
+        call("svae_stream_wait_event", stream.cuda_stream, ev.h)
+    else:
+        stream.wait_event(ev)
 
 
 class DispatchTimer:

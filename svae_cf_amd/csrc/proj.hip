@@ -1206,6 +1206,27 @@ extern "C" int svae_event_create(void** out) {
     *out = (void*)e;
     return 0;
 }
+// Ordering events of the step's streams (host helpers, no counterpart in the reference): an event without timing,
+// its record on a stream and a stream's wait for it -- the three HIP calls, without the 10-14 us of host time that
+// the torch wrappers of the same calls cost (a step records 9 and waits for 11: 0.16 of its 0.45 ms of host time).
+extern "C" int svae_sync_event_create(void** out) {
+    if (!out) return svae_fail(-1, "svae_sync_event_create: null pointer");
+    hipEvent_t e = nullptr;
+    hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) return svae_fail((int)rc, "svae_sync_event_create: %s", hipGetErrorString(rc));
+    *out = (void*)e;
+    return 0;
+}
+extern "C" int svae_event_record(void* e, void* stream) {
+    hipError_t rc = hipEventRecord((hipEvent_t)e, (hipStream_t)stream);
+    if (rc != hipSuccess) return svae_fail((int)rc, "svae_event_record: %s", hipGetErrorString(rc));
+    return 0;
+}
+extern "C" int svae_stream_wait_event(void* stream, void* e) {
+    hipError_t rc = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e, 0);
+    if (rc != hipSuccess) return svae_fail((int)rc, "svae_stream_wait_event: %s", hipGetErrorString(rc));
+    return 0;
+}
 extern "C" int svae_event_destroy(void* e) {
     hipError_t rc = hipEventDestroy((hipEvent_t)e);
     if (rc != hipSuccess) return svae_fail((int)rc, "svae_event_destroy: %s", hipGetErrorString(rc));

@@ -142,6 +142,7 @@ class SVAEEngine:
         self.gi_split = os.environ.get("SVAE_GI_SPLIT", "1") == "1"
         self.bptt_split = os.environ.get("SVAE_BPTT_SPLIT", "0") == "1"
         self.fdh_q0 = int(os.environ.get("SVAE_FDH_Q0", "4"))  # nominal split count of the forward sweep (_proj_sched)
+        self._sevs = {}                # purpose -> _lib.SyncEvent, re-recorded every step
         self._sched_cache = {}         # tile-count shape -> (device table, nwg, ns_q, ns_rem), see _proj_sched
         self.dw_q = int(os.environ.get("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
         self.head_fused = os.environ.get("SVAE_HEAD_FUSED", "1") == "1"
@@ -176,7 +177,7 @@ class SVAEEngine:
     def _settle(self):
         """Order the caller's stream behind work a train_step left floating on the w3 stream."""
         if self._w3_event is not None:
-            torch.cuda.current_stream().wait_event(self._w3_event)
+            _lib.stream_wait(torch.cuda.current_stream(), self._w3_event)
             self._w3_event = None
             self._float_plan = None
 
@@ -283,6 +284,13 @@ class SVAEEngine:
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(i)
 
+    def _sev(self, name):
+        """The ordering event kept for `name` (one per purpose: a wait refers to the record before it in host order)."""
+        ev = self._sevs.get(name)
+        if ev is None:
+            ev = self._sevs[name] = _lib.SyncEvent()
+        return ev
+
     def _side_stream(self, which=0, cur=None):
         """Stream `which` (0, 1) of the overlapped work.  HIP maps streams onto a few hardware queues (4 per
         process here) and two streams that share a queue run IN ORDER: a side stream that landed on the caller's
@@ -381,7 +389,7 @@ class SVAEEngine:
         w, st = self.ws, _stream()
         self._plan, self._anneal = plan, float(anneal)
         if getattr(plan, "ready", None) is not None:      # uploaded on a copy stream (batch.PlanPrefetcher)
-            cur.wait_event(plan.ready)
+            _lib.stream_wait(cur, plan.ready)
             plan.ready = None
             # its buffers were allocated on that stream: tell the allocator which streams read them, or a later
             # upload could reuse the memory while this step's kernels are still running
@@ -394,7 +402,7 @@ class SVAEEngine:
         eps_done = False
         if self.fused and self.overlap:
             side = self._side_stream(cur=cur)
-            step_begin = torch.cuda.Event()
+            step_begin = self._sev("step_begin")
             step_begin.record(cur)
         # the caller's stream first: its kernels head the critical path, the side stream's are not needed before the
         # decoder side
@@ -424,7 +432,7 @@ class SVAEEngine:
                       self.prec, st)
             self._toc("gi_gemm", ev)
             if gi_split:
-                head_done = torch.cuda.Event()
+                head_done = self._sev("head_done")
                 head_done.record(cur)
         else:
             self._gemm(w["emb"], self.P("gru.weight_ih_l0"), w["gi"], R, G, E, E, E, G, 0, 0,
@@ -449,7 +457,7 @@ class SVAEEngine:
         # kernel trace).
         if t1 > 0:
             gru_range(0, t1, "gru_fwd")
-            first_done = torch.cuda.Event()
+            first_done = self._sev("first_done")
             first_done.record(cur)
         else:
             gru_range(0, plan.Tmax, "gru_fwd")
@@ -457,35 +465,35 @@ class SVAEEngine:
         if side_prep:
             # everything that depends on the parameters only (bf16 operand copies, weight fragments, W_hh^T, the
             # zero fill of the embedding gradient) runs on the side stream beside the embedding / GRU kernels
-            side.wait_event(step_begin)
+            _lib.stream_wait(side, step_begin)
             with _Launch(side, self._torch_ctx()):
                 self._param_prep(want_grad)
                 if eps is None:               # the noise depends on the plan and the step only
                     _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
                               int(step) & 0xFFFFFFFF, _stream())
                     eps_done = True
-                params_ready = torch.cuda.Event()
+                params_ready = self._sev("params_ready")
                 params_ready.record(side)
                 if gi_split:
                     # (behind the parameter preparation: the decoder side of the first range waits for that, the
                     #  second recurrence, which needs these rows, only starts when the first one has ended)
                     _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr() + 4 * gi_split,
                               w["emb"].data_ptr() + 4 * E * gi_split, R - gi_split, self.I, _stream())
-                    side.wait_event(head_done)          # (the W_ih fragments)
+                    _lib.stream_wait(side, head_done)          # (the W_ih fragments)
                     _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr() + 4 * E * gi_split, E,
                               self.wih_frags[0].data_ptr(), self.P("gru.bias_ih_l0").data_ptr(),
                               w["gi"].data_ptr() + 4 * G * gi_split, R - gi_split, 0, self.prec, _stream())
                 if t1 > 0:
-                    side.wait_event(first_done)
+                    _lib.stream_wait(side, first_done)
                     gru_range(t1, plan.Tmax, "gru_fwd2")
                     if self.mlp2_side and self._w3_event is not None:
                         # the MLP chain of the second range's rows here, behind their recurrence, on the CUs it has
                         # just freed: the caller's stream is still in the first range's sweep (the floated
                         # decoder.linear2 work of the step before read d1 / h2b, which this overwrites)
-                        side.wait_event(self._w3_event)
+                        _lib.stream_wait(side, self._w3_event)
                     if self.mlp2_side:
                         self._decoder_rows(plan, r1, R, self._ncu, sweep=False)
-                    second_done = torch.cuda.Event()
+                    second_done = self._sev("second_done")
                     second_done.record(side)
         if eps is not None:
             if eps.numel() != R * L:
@@ -497,19 +505,19 @@ class SVAEEngine:
         if self.fused:
             # encoder -> (mu | log_sigma) -> z, KL -> decoder hidden in one kernel (bf16 MFMA mode)
             if params_ready is not None:
-                cur.wait_event(params_ready)
+                _lib.stream_wait(cur, params_ready)
             else:
                 self._param_prep(want_grad)
             if self._w3_event is not None:
                 # the last step's floated decoder.linear2 work: it read d1 / h2b / h2tb, which the kernels below
                 # overwrite, and it made the operand copies of the new weights, which they read
-                cur.wait_event(self._w3_event)
+                _lib.stream_wait(cur, self._w3_event)
                 self._w3_event = None
                 self._float_plan = None       # (kept alive until here: the floated kernels read its tables)
             if t1 > 0:
                 self._last_fused = True
                 self._decoder_rows(plan, 0, r1, self._ncu - (plan.B + 3) // 4)
-                cur.wait_event(second_done)
+                _lib.stream_wait(cur, second_done)
                 self._decoder_rows(plan, r1, R, self._ncu, mlp=not self.mlp2_side)
                 self._fused_grad = True
                 if defer_loss and self.overlap:
@@ -839,7 +847,7 @@ class SVAEEngine:
         if side is None:
             decoder_side_wgrads(self.slabs)
         else:
-            chain_done = torch.cuda.Event()
+            chain_done = self._sev("chain_done")
             chain_done.record(cur)
         # GRU (BPTT)
         prepped = self.fused and self._prepped_grad
@@ -876,7 +884,7 @@ class SVAEEngine:
             gargs = (w["dhs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(), self.whh_t.data_ptr(),
                      plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax)
             _lib.call("svae_gru_bwd_range_bf16out", *gargs, tb, plan.Tmax, dgi.data_ptr(), self.dh_carry.data_ptr(), st)
-            late_done = torch.cuda.Event()
+            late_done = self._sev("late_done")
             late_done.record(cur)
             _lib.call("svae_gru_bwd_range_bf16out", *gargs, 0, tb, dgi.data_ptr(), self.dh_carry.data_ptr(), st)
         elif dg16:
@@ -891,11 +899,11 @@ class SVAEEngine:
         if side is not None:
             # gated on the chain above, enqueued after the recurrence so that its few workgroups get their CUs
             # first; the weight-gradient kernels then take whatever the recurrence leaves idle
-            side.wait_event(chain_done)
+            _lib.stream_wait(side, chain_done)
             floating = self._in_step and self.float_w3 and self._last_fused
             if floating:
                 w3 = self._side_stream(1, cur=cur)
-                w3.wait_event(chain_done)
+                _lib.stream_wait(w3, chain_done)
                 with _Launch(w3, self._torch_ctx()):
                     proj_dw(w["pslabs_side"])
                     # (its bucket's all-reduce is issued by train_step AFTER the other buckets': collectives run in
@@ -956,7 +964,7 @@ class SVAEEngine:
             # the two GRU weight gradients behind the dense-layer ones on the side stream (idle by the time the BPTT
             # ends), beside dL/demb -> scatter-add on the caller's: the caller's queue is the step's critical path
             # (host order: the caller's kernels first -- its queue must not run dry while the side launches are made)
-            bptt_done = torch.cuda.Event()
+            bptt_done = self._sev("bptt_done")
             bptt_done.record(cur)
             embedding_grad()
             if self._early_opt is not None:
@@ -967,7 +975,7 @@ class SVAEEngine:
                 (s_, e_), gscale_, count_ = self._early_opt
                 self._adam_range(s_, e_, gscale_, st, count=count_)
                 self._early_opt = False          # (done: train_step leaves this bucket out)
-            side.wait_event(bptt_done)
+            _lib.stream_wait(side, bptt_done)
             with _Launch(side, self._torch_ctx()):
                 gru_wgrads()          # (one of the two here and one on the caller's stream: no better, 0.922 vs 0.918)
         elif self.tail_embedding_first:
@@ -977,7 +985,9 @@ class SVAEEngine:
             gru_wgrads()
             embedding_grad()
         if side is not None:
-            cur.wait_stream(side)
+            joined = self._sev("side_joined")
+            joined.record(side)
+            _lib.stream_wait(cur, joined)
         elif self._loss_deferred:
             _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
@@ -1011,16 +1021,16 @@ class SVAEEngine:
                       w["demb"].data_ptr() + 4 * E * r0, r1 - r0, _stream())
             self._toc("demb_gemm", ev)
 
-        early_done = torch.cuda.Event()
+        early_done = self._sev("early_done")
         early_done.record(cur)
         demb(0, rb)                                   # the caller's stream: rows of the early timesteps
-        side.wait_event(late_done)
+        _lib.stream_wait(side, late_done)
         with _Launch(side, self._torch_ctx()):
             demb(rb, R)
-            late_demb = torch.cuda.Event()
+            late_demb = self._sev("late_demb")
             late_demb.record(side)
             wgrads(rb, R, 0, ns_a)
-        cur.wait_event(late_demb)
+        _lib.stream_wait(cur, late_demb)
         ge = self.Gv("item_embed.weight")
         self._prepped_grad = False
         _lib.call("svae_embed_bwd", w["demb"].data_ptr(), plan.perm.data_ptr(), plan.seg_off.data_ptr(),
@@ -1030,7 +1040,7 @@ class SVAEEngine:
             gs.rows_ready(plan.seg_item, plan.nseg)
         else:
             self._bucket(2)
-        side.wait_event(early_done)
+        _lib.stream_wait(side, early_done)
         with _Launch(side, self._torch_ctx()):
             wgrads(0, rb, ns_a, ns - ns_a)
             for name, X, K, slabs, _ in jobs:
@@ -1189,7 +1199,7 @@ class SVAEEngine:
             else:
                 self._adam_range(s0, e0, gscale, _stream())
             self._proj_prep_items(_stream())
-        self._w3_event = torch.cuda.Event()
+        self._w3_event = self._sev("w3")
         self._w3_event.record(w3)
         self._w3_fresh = True
         self._float_plan = plan
