@@ -249,6 +249,21 @@ int svae_proj_nll_bwd_dw_split(const void* w3s, const void* h2b, const void* h2t
 /* Timing hooks (measurement only; no counterpart in the reference): svae_proj_time_next arms the calling thread's next
  * sweep launch with start / stop events (from svae_event_create) attached to the dispatch itself; read the kernel's
  * duration with svae_event_elapsed_ms (synchronises on the stop event). */
+/* ---- collectives for hosts without torch.distributed (thin RCCL wrappers taking the communicator) ----
+ * No counterpart in the reference (single process).  librccl is loaded on first use.  svae_rccl_unique_id: 128 bytes
+ * made by rank 0 and handed to every rank; svae_rccl_comm_create: one communicator per process and GPU (collective
+ * over the nranks callers).  The exchanges are in place on the flat gradient / parameter buffers and are enqueued
+ * on `stream`: the sum all-reduce of a bucket; for the sharded decoder.linear2 bucket (nranks shards of shard_count
+ * floats) the reduce-scatter that leaves rank r's shard of the sum at bucket + r * shard_count and, after the
+ * optimizer step over that shard, the all-gather of the parameter shards.  Errors: < 0 argument / loader errors,
+ * 1000 + ncclResult_t for RCCL's own. */
+int svae_rccl_unique_id(void* out128);
+int svae_rccl_comm_create(void** comm, int nranks, int rank, const void* id128);
+int svae_rccl_comm_destroy(void* comm);
+int svae_allreduce_sum_f32(void* comm, float* buf, long long count, void* stream);
+int svae_reduce_scatter_sum_f32(void* comm, float* bucket, long long shard_count, int rank, void* stream);
+int svae_allgather_f32(void* comm, float* bucket, long long shard_count, int rank, void* stream);
+
 int svae_event_create(void** out_event);
 /* Ordering events between the step's streams (host helpers, no counterpart in the reference): an event without
  * timing, its record on a stream, a stream's wait for it. */

@@ -56,6 +56,12 @@ SIGNATURES = {
     "svae_mlp_fwd_prep": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "svae_mlp_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "svae_spin": [_I, _P],
+    "svae_rccl_unique_id": [_P],
+    "svae_rccl_comm_create": [_P, _I, _I, _P],
+    "svae_rccl_comm_destroy": [_P],
+    "svae_allreduce_sum_f32": [_P, _P, _LL, _P],
+    "svae_reduce_scatter_sum_f32": [_P, _P, _LL, _I, _P],
+    "svae_allgather_f32": [_P, _P, _LL, _I, _P],
     "svae_event_create": [_P],
     "svae_sync_event_create": [_P],
     "svae_event_record": [_P, _P],

@@ -178,3 +178,34 @@ def test_sharded_evaluate_equals_single_process():
             assert m == m0, (r, m, m0)
             assert lm == lm0
     assert ref[0][0]["NDCG@100"] > 0 and ref[1][0]["loss"] > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# the C-ABI's own collectives (svae_rccl_* / svae_allreduce_sum_f32 / reduce-scatter / all-gather): RCCL at world size 1
+# ---------------------------------------------------------------------------------------------
+def test_c_abi_rccl_wrappers_world_size_one():
+    """The thin RCCL wrappers of the C-ABI (hosts without torch.distributed), on the one GPU there is: a communicator
+    of one rank from a unique id, the in-place sum all-reduce of a bucket (identity at one rank), and the
+    reduce-scatter / all-gather pair of the sharded bucket (one shard = the bucket).  Checks the call path -- library
+    loading, argument order, stream ordering -- not a multi-GPU result, which needs hardware this box does not have."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    from svae_cf_amd import _lib
+    uid = (ctypes.c_char * 128)()
+    _lib.call("svae_rccl_unique_id", ctypes.cast(uid, ctypes.c_void_p))
+    assert any(b != b"\x00" for b in uid)
+    comm = ctypes.c_void_p()
+    _lib.call("svae_rccl_comm_create", ctypes.byref(comm), 1, 0, ctypes.cast(uid, ctypes.c_void_p))
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        g = torch.randn(4096 + 512, device="cuda")
+        want = g.clone()
+        _lib.call("svae_allreduce_sum_f32", comm, g.data_ptr(), g.numel(), st)
+        _lib.call("svae_reduce_scatter_sum_f32", comm, g.data_ptr(), g.numel(), 0, st)
+        _lib.call("svae_allgather_f32", comm, g.data_ptr(), g.numel(), 0, st)
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+        with pytest.raises(_lib.SvaeHipError):
+            _lib.call("svae_allreduce_sum_f32", comm, g.data_ptr(), 0, st)
+    finally:
+        _lib.call("svae_rccl_comm_destroy", comm)
