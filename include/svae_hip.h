@@ -43,6 +43,11 @@ int svae_gemm(const float* A, const float* B, float* C, const float* bias, const
               int N, int K, int lda, int ldb, int ldc, int ldaux, int a_layout, int b_layout, int act, int prec,
               int nsplit, long long slab_stride, void* stream);
 int svae_reduce_slabs(const float* slabs, float* out, long long n, int nsplit, long long slab_stride, void* stream);
+/* Decoder.linear2 as Model.forward returns it (nb:710, nb:752-768): dense logits of n rows of the decoder hidden,
+ * logits[r][i] = h2[r] . W3[i] + b3[i]  (h2 [n][160], W3 [I][160], logits [n][ldl]).  The notebook surface and
+ * evaluate() rank these; training never materialises them.  prec 0: exact fp32, 1: bf16 operands. */
+int svae_logits_fwd(const float* h2, const float* w3, const float* b3, float* logits, int n, int I, int ldl, int prec,
+                    void* stream);
 /* Weight + bias gradient of a Linear layer (autograd of y = x W^T + b, nb:1205), bf16 MFMA path:
  * gW[n][k] = sum_r dy[r][n] x[r][k], gb[n] = sum_r dy[r][n].  The rows are split nsplit ways; split z writes
  * gW at out + z*slab_stride and gb at colsum + z*slab_stride (colsum may be NULL); sum with svae_reduce_slabs.

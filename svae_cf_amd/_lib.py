@@ -20,6 +20,7 @@ _U = _c.c_uint
 # name -> argtypes (all return int: 0 ok, <0 argument error, >0 hipError_t)
 SIGNATURES = {
     "svae_gemm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _P],
+    "svae_logits_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "svae_reduce_slabs": [_P, _P, _LL, _I, _LL, _P],
     "svae_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _LL, _P],
     "svae_gru_fwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P],

@@ -378,3 +378,14 @@ extern "C" int svae_reduce_slabs(const float* slabs, float* out, long long n, in
     SV_LAUNCH_CHECK();
     return 0;
 }
+
+// Reference interface replaced: Decoder.linear2 (nb:710) as Model.forward returns it -- the dense logits
+// dec_out[r][i] = sum_k h2[r][k] W3[i][k] + b3[i] of n rows of the decoder hidden (h2 [n][160], rows of 150 values
+// padded with zeros; W3 [I][160] as stored in the flat parameter buffer; logits [n][ldl], ldl >= I).  The notebook
+// surface and evaluate() call it for the rows they rank; the training step never materialises logits.
+// prec 0: exact fp32 MFMA (the parity mode), 1: bf16 operands.
+extern "C" int svae_logits_fwd(const float* h2, const float* w3, const float* b3, float* logits, int n, int I, int ldl,
+                               int prec, void* stream) {
+    SV_CHECK_ARG(h2 && w3 && b3 && logits && n > 0 && I > 0 && ldl >= I, "svae_logits_fwd: bad arguments");
+    return svae_gemm(h2, w3, logits, b3, nullptr, nullptr, n, I, SV_DP, SV_DP, SV_DP, ldl, 0, 0, 0, 0, prec, 1, 0, stream);
+}

@@ -766,8 +766,8 @@ class SVAEEngine:
             _lib.call("svae_gather_rows", self.ws["d1"].data_ptr(), rows_idx.data_ptr(), src.data_ptr(),
                       n, DP, DP, DP, st)
         out = torch.empty(n * self.IP, **f32)
-        self._gemm(src, self.P("decoder.linear2.weight"), out, n, self.I, DP, DP, DP, self.IP, 0, 0,
-                   bias=self.P("decoder.linear2.bias"))
+        _lib.call("svae_logits_fwd", src.data_ptr(), self.P("decoder.linear2.weight").data_ptr(),
+                  self.P("decoder.linear2.bias").data_ptr(), out.data_ptr(), n, self.I, self.IP, self.gemm_prec, st)
         return out.view(n, self.IP)
 
     def logits_rows(self, R):
