@@ -220,9 +220,16 @@ int svae_wgrad_cols_prec(const float* dy, const float* x, float* out, float* col
                          void* stream);
 int svae_rowgemm_prep_prec(const float* wih, int which, void* frags, int prec, void* stream);
 /* svae_embed_fwd over rows [0, R) and svae_rowgemm_prep_prec(wih, 0, frags, 1) in ONE launch: the two independent
- * kernels that head a training step (reference: nn.Embedding call nb:756, the GRU's input weights nb:724). */
-int svae_embed_fwd_wih_prep(const float* table, const int* x, float* out, int R, int I, const float* wih, void* frags,
-                            void* stream);
+ * kernels that head a training step (reference: nn.Embedding call nb:756, the GRU's input weights nb:724).
+ * out_bf16 != 0: the gathered rows are written as bf16 ([R][256] two-byte elements) -- what both consumers of the rows
+ * round them to anyway -- for svae_rowgemm_gi_bf16x (gi = emb W_ih^T + b_ih) and svae_wgrad_cols_bf16dy_bf16x (the
+ * input-weight gradient), bit-identical to the fp32-row forms.  svae_embed_fwd_bf16: the gather alone, bf16 rows. */
+int svae_embed_fwd_wih_prep(const float* table, const int* x, void* out, int R, int I, const float* wih, void* frags,
+                            int out_bf16, void* stream);
+int svae_embed_fwd_bf16(const float* table, const int* x, void* out16, int R, int I, void* stream);
+int svae_rowgemm_gi_bf16x(const void* x16, int ldx, const void* frags, const float* bias, float* y, int R, void* stream);
+int svae_wgrad_cols_bf16dy_bf16x(const void* dy16, const void* x16, float* out, float* colsum, int R, int N, int K, int ldy,
+                                 int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream);
 int svae_rowgemm_ld_prec(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,
                          int prec, void* stream);
 int svae_mlp_prep_prec(const float* w1, const float* wl, const float* w2, void* frags, int prec, void* stream);

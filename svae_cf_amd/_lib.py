@@ -28,7 +28,10 @@ SIGNATURES = {
     "svae_proj_prep_rows_range": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
     "svae_gru_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "svae_embed_fwd": [_P, _P, _P, _I, _I, _P],
-    "svae_embed_fwd_wih_prep": [_P, _P, _P, _I, _I, _P, _P, _P],
+    "svae_embed_fwd_wih_prep": [_P, _P, _P, _I, _I, _P, _P, _I, _P],
+    "svae_embed_fwd_bf16": [_P, _P, _P, _I, _I, _P],
+    "svae_rowgemm_gi_bf16x": [_P, _I, _P, _P, _P, _I, _P],
+    "svae_wgrad_cols_bf16dy_bf16x": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _LL, _I, _I, _P],
     "svae_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "svae_embed_long_rows": [],
     "svae_proj_occ_long": [],

@@ -225,11 +225,12 @@ __global__ void rowgemm_prep_kernel(const float* __restrict__ src, int sn, int s
 // work, one wave per fragment).  They are independent of each other and both head the step's critical path: one
 // launch gap instead of two.
 constexpr int RG_PREP0_FRAGS = (SV_G / 32) * (SV_E / 16);
+template <bool OUT16>
 __global__ __launch_bounds__(256) void embed_wih_prep_kernel(const float* __restrict__ table, const int* __restrict__ x,
                                                              float* __restrict__ out, int R, int I,
                                                              const float* __restrict__ wih,
-                                                             unsigned short* __restrict__ frags) {
-    constexpr int PREP_BLOCKS = RG_PREP0_FRAGS / 4;
+                                                             unsigned short* __restrict__ frags, int nprep) {
+    const int PREP_BLOCKS = nprep;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((int)blockIdx.x < PREP_BLOCKS) {
         using S = RgShape<0>;
@@ -249,7 +250,13 @@ __global__ __launch_bounds__(256) void embed_wih_prep_kernel(const float* __rest
         const int it = x[row];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (it >= 0 && it < I) v = reinterpret_cast<const float4*>(table + (size_t)it * SV_E)[lane];
-        reinterpret_cast<float4*>(out + (size_t)row * SV_E)[lane] = v;
+        if (OUT16) {      // bf16 rows (512 B): what both consumers of the rows round them to anyway
+            uint2 u;
+            u.x = rg_pk2(v.x, v.y); u.y = rg_pk2(v.z, v.w);
+            reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + (size_t)row * SV_E)[lane] = u;
+        } else {
+            reinterpret_cast<float4*>(out + (size_t)row * SV_E)[lane] = v;
+        }
     }
 }
 
@@ -275,16 +282,28 @@ int rg_launch(RgArgs a, hipStream_t st) {
 
 // svae_embed_fwd (rows [0, R) of the plan) and svae_rowgemm_prep_prec(wih, 0, frags, 1) in one launch (bf16 mode).
 // Reference: nn.Embedding call nb:756; the fragments are this build's operand form of gru.weight_ih_l0 (nb:724).
-extern "C" int svae_embed_fwd_wih_prep(const float* table, const int* x, float* out, int R, int I, const float* wih,
-                                       void* frags, void* stream) {
-    SV_CHECK_ARG(table && x && out && wih && frags && R > 0 && I > 0, "svae_embed_fwd_wih_prep: bad arguments");
+// out_bf16 != 0: `out` receives bf16 rows ([R][256] elements of 2 bytes) for svae_rowgemm_gi_bf16x /
+// svae_wgrad_cols_bf16dy_bf16x; wih == NULL: the gather alone (svae_embed_fwd_bf16).
+extern "C" int svae_embed_fwd_wih_prep(const float* table, const int* x, void* out, int R, int I, const float* wih,
+                                       void* frags, int out_bf16, void* stream) {
+    SV_CHECK_ARG(table && x && out && R > 0 && I > 0 && ((wih == nullptr) == (frags == nullptr)),
+                 "svae_embed_fwd_wih_prep: bad arguments");
     static_assert(RG_PREP0_FRAGS % 4 == 0, "four fragments per workgroup");
     int gather_blocks = (R + 3) / 4;
     if (gather_blocks > 8192) gather_blocks = 8192;     // grid-stride beyond that
-    hipLaunchKernelGGL(embed_wih_prep_kernel, dim3(RG_PREP0_FRAGS / 4 + gather_blocks), dim3(256), 0, (hipStream_t)stream,
-                       table, x, out, R, I, wih, (unsigned short*)frags);
+    const int nprep = wih ? RG_PREP0_FRAGS / 4 : 0;
+    if (out_bf16)
+        hipLaunchKernelGGL(embed_wih_prep_kernel<true>, dim3(nprep + gather_blocks), dim3(256), 0, (hipStream_t)stream,
+                           table, x, (float*)out, R, I, wih, (unsigned short*)frags, nprep);
+    else
+        hipLaunchKernelGGL(embed_wih_prep_kernel<false>, dim3(nprep + gather_blocks), dim3(256), 0, (hipStream_t)stream,
+                           table, x, (float*)out, R, I, wih, (unsigned short*)frags, nprep);
     SV_LAUNCH_CHECK();
     return 0;
+}
+// The gather alone with bf16 rows out (the second time range's rows, on the side stream).
+extern "C" int svae_embed_fwd_bf16(const float* table, const int* x, void* out16, int R, int I, void* stream) {
+    return svae_embed_fwd_wih_prep(table, x, out16, R, I, nullptr, nullptr, 1, stream);
 }
 
 extern "C" int svae_rowgemm_frag_elems(int which) {
@@ -338,6 +357,17 @@ extern "C" int svae_rowgemm_ld_prec(const float* x, int ldx, const void* frags, 
     if (prec == 2)
         return which == 0 ? rg_launch<0, false, true>(a, (hipStream_t)stream) : rg_launch<1, false, true>(a, (hipStream_t)stream);
     return which == 0 ? rg_launch<0, false>(a, (hipStream_t)stream) : rg_launch<1, false>(a, (hipStream_t)stream);
+}
+
+// which 0 with x as bf16 elements (the embedding rows as svae_embed_fwd_bf16 / svae_embed_fwd_wih_prep wrote them):
+// gi = emb W_ih^T + b_ih, bit-identical to the fp32-row form (which rounds the rows to bf16 itself, RNE as the gather).
+extern "C" int svae_rowgemm_gi_bf16x(const void* x, int ldx, const void* frags, const float* bias, float* y, int R,
+                                     void* stream) {
+    SV_CHECK_ARG(x && frags && y && R > 0 && ldx >= SV_E && (ldx % 8) == 0, "svae_rowgemm_gi_bf16x: bad arguments");
+    SV_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
+                 "svae_rowgemm_gi_bf16x: operands must be 16-byte aligned");
+    RgArgs a{(const float*)x, (const unsigned short*)frags, bias, y, R, 0, ldx, nullptr};
+    return rg_launch<0, true>(a, (hipStream_t)stream);
 }
 
 // which 1 with x as bf16 elements (the GRU's merged gradient array): ldx in elements, a multiple of 8.

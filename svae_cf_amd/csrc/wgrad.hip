@@ -61,9 +61,13 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
 
 // SPLIT (fp32 dY only): the parity instantiation -- same staging, tiling and slab order, every product carried by
 // the six leading terms of (hi + mid + lo) x (hi + mid + lo).
-template <bool ABF, bool SPLIT = false>
+// XBF: X holds bf16 elements as well (the embedding rows as the gather wrote them: its consumers round to bf16 anyway,
+// RNE there as here, so the gradient is bit-identical): the X tile is 4 KiB, one piece per wave, and the six
+// re-reads of X from L2 that bound this kernel (header) are half the bytes.
+template <bool ABF, bool SPLIT = false, bool XBF = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     static_assert(!(ABF && SPLIT), "the split instantiation reads fp32 operands");
+    static_assert(!XBF || ABF, "bf16 X comes with the bf16 dY");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,12 +85,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     if (t_end > ntiles) t_end = ntiles;
 
     const __amdgpu_buffer_rsrc_t dyb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((size_t)a.R * a.ldy * (ABF ? 2 : 4)), BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((size_t)a.R * a.ldx * 4), BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((size_t)a.R * a.ldx * (XBF ? 2 : 4)), BUF_FLAGS);
     // one piece = one wave-instruction = 2 tile rows x 128 columns; a tile is 8 pieces per operand, wave w
     // issues pieces w and w + 4 of both.  Columns beyond the operand's width fall into the next row (finite
     // garbage that only reaches output rows / columns that are never stored) or beyond the buffer (zeros).
     const int ca = ABF ? m0 + 8 * (lane & 15) : m0 + 4 * (lane & 31);
-    const unsigned colA = (unsigned)(ca + (ca >= a.remap_from ? a.remap_add : 0)) * (ABF ? 2u : 4u), colB = (unsigned)(n0 + 4 * (lane & 31)) * 4u;
+    const unsigned colA = (unsigned)(ca + (ca >= a.remap_from ? a.remap_add : 0)) * (ABF ? 2u : 4u), colB = XBF ? (unsigned)(n0 + 8 * (lane & 15)) * 2u : (unsigned)(n0 + 4 * (lane & 31)) * 4u;
     const unsigned rowl = (unsigned)(lane >> 5);
     const unsigned rowa = (unsigned)(lane >> 4);      // ABF: row of the lane inside its 4-row piece
 #define SV_WG_STAGE(t_, st_)                                                                                   \
@@ -102,10 +106,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)(l_ + 4096), 16, \
                                                      (r0_ + 8) * (unsigned)a.ldy * 4u + colA, 0, 0, 0);         \
         }                                                                                                      \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES), 16, \
-                                                 r0_ * (unsigned)a.ldx * 4u + colB, 0, 0, 0);                   \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES + 4096), 16, \
-                                                 (r0_ + 8) * (unsigned)a.ldx * 4u + colB, 0, 0, 0);             \
+        if (XBF) {                                                                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES), 16, \
+                                                     ((unsigned)(t_) * WK + 4 * wave + rowa) * (unsigned)a.ldx * 2u + colB, 0, 0, 0); \
+        } else {                                                                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES), 16, \
+                                                     r0_ * (unsigned)a.ldx * 4u + colB, 0, 0, 0);               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES + 4096), 16, \
+                                                     (r0_ + 8) * (unsigned)a.ldx * 4u + colB, 0, 0, 0);         \
+        }                                                                                                      \
     }
 
     f32x16 acc[2][2];
@@ -128,8 +137,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int st = (t - t_begin) & (NST - 1);
         // own pieces of tile t landed (tiles t+1, t+2 may still be in flight: 8 younger pieces)
         // (pieces per tile and wave: 2 + 2, or 1 + 2 with a bf16 dY)
-        if (t + 2 < t_end) { if (ABF) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-        else if (t + 1 < t_end) { if (ABF) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        // (pieces per tile and wave: 2 + 2; 1 + 2 with a bf16 dY; 1 + 1 with a bf16 X as well)
+        if (t + 2 < t_end) {
+            if (XBF) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (ABF) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (t + 1 < t_end) {
+            if (XBF) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (ABF) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();       // tile t complete; everyone is done reading tile t-1's stage
@@ -166,7 +183,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float* p = sB + (8 * lh) * WN + wn + 32 * j + li;
-            if (SPLIT) {
+            if (XBF) {
+                const unsigned short* q = reinterpret_cast<const unsigned short*>(sB) + (8 * lh) * WN + wn + 32 * j + li;
+                uint4 u;
+                u.x = (unsigned)q[0] | ((unsigned)q[WN] << 16); u.y = (unsigned)q[2 * WN] | ((unsigned)q[3 * WN] << 16);
+                u.z = (unsigned)q[4 * WN] | ((unsigned)q[5 * WN] << 16); u.w = (unsigned)q[6 * WN] | ((unsigned)q[7 * WN] << 16);
+                fb[j] = __builtin_bit_cast(bf16x8, u);
+            } else if (SPLIT) {
                 const float v[8] = {p[0], p[WN], p[2 * WN], p[3 * WN], p[4 * WN], p[5 * WN], p[6 * WN], p[7 * WN]};
                 split8(v, fb[j], fbm[j], fbl[j]);
             } else {
@@ -239,6 +262,16 @@ extern "C" int svae_wgrad_cols(const float* dy, const float* x, float* out, floa
                                int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream) {
     return wgrad_launch(dy, 0, x, out, colsum, R, N, K, ldy, ldx, nsplit, slab_stride, remap_from, remap_add, stream);
 }
+// dy AND x hold bf16 elements (x: the embedding rows as svae_embed_fwd_bf16 wrote them; ldx in elements, a multiple
+// of 8): the GRU's input-weight gradient with half the bytes of its re-read operand.
+extern "C" int svae_wgrad_cols_bf16dy_bf16x(const void* dy, const void* x, float* out, float* colsum, int R, int N, int K,
+                                            int ldy, int ldx, int nsplit, long long slab_stride, int remap_from,
+                                            int remap_add, void* stream) {
+    SV_CHECK_ARG((ldy % 8) == 0 && (ldx % 8) == 0 && (remap_from % 8) == 0 && (remap_add % 8) == 0,
+                 "svae_wgrad_cols_bf16dy_bf16x: bad alignment");
+    return wgrad_launch(dy, 3, (const float*)x, out, colsum, R, N, K, ldy, ldx, nsplit, slab_stride, remap_from, remap_add,
+                        stream);
+}
 // dy holds bf16 elements (ldy in elements, a multiple of 8; remap_from / remap_add multiples of 8).
 extern "C" int svae_wgrad_cols_bf16dy(const void* dy, const float* x, float* out, float* colsum, int R, int N, int K,
                                       int ldy, int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add,
@@ -272,10 +305,15 @@ static int wgrad_launch(const void* dy_, int dy_bf16, const float* x, float* out
             e = hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)wgrad_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)wgrad_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
         if (e != hipSuccess) return svae_fail((int)e, "svae_wgrad: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    if (dy_bf16 == 2)
+    if (dy_bf16 == 3)
+        hipLaunchKernelGGL((wgrad_kernel<true, false, true>), dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
+                           (hipStream_t)stream, a);
+    else if (dy_bf16 == 2)
         hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
                            (hipStream_t)stream, a);
     else if (dy_bf16)

@@ -146,6 +146,10 @@ class SVAEEngine:
         self._sched_cache = {}         # tile-count shape -> (device table, nwg, ns_q, ns_rem), see _proj_sched
         self.dw_q = int(os.environ.get("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
         self.head_fused = os.environ.get("SVAE_HEAD_FUSED", "1") == "1"
+        # bf16 mode: the gathered embedding rows are kept as bf16 (their two consumers -- the input-gate GEMM and the
+        # input-weight gradient -- round them to bf16 anyway: bit-identical) -- half the bytes written by the gather,
+        # read by the GEMM and re-read six times from L2 by the weight-gradient kernel
+        self.emb16 = os.environ.get("SVAE_EMB16", "1") == "1"
         self.mlp2_side = os.environ.get("SVAE_MLP2_SIDE", "1") == "1"
         self.early_embed_opt = os.environ.get("SVAE_EARLY_EMBED_OPT", "0") == "1"
         self._early_opt = None         # train_step -> backward: (range, gscale, step number) of the embedding bucket
@@ -226,6 +230,7 @@ class SVAEEngine:
             capp = (cap + 63) // 64 * 64
             self.capp = capp
             self.ws["dg4b"] = torch.zeros((cap + 1) * 4 * HP, **bf)
+            self.ws["emb16"] = torch.zeros((cap + 1) * E, **bf)       # the gathered rows as bf16 (self.emb16)
             # (split instantiation: every bf16 image is followed by its mid and lo parts, one part stride apart)
             m = 3 if self.split else 1
             self.ws["h2b"] = torch.zeros(m * capp * DP, **bf)
@@ -334,7 +339,7 @@ class SVAEEngine:
         self.side_stream_info.append(dict(tried=tries, all_us=times[best], concurrent=False))
         return cands[best]
 
-    def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx, slabs=None, remap=None, dy_bf16=False):
+    def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx, slabs=None, remap=None, dy_bf16=False, x_bf16=False):
         """Weight + bias gradient of y = x W^T + b in one pass: gW[N][K] = dY[R][N]^T X[R][K] and
         gb[N] = column sums of dY (folded into the GEMM).  Split-K over rows writes one slab per split
         (weights then bias), summed in a fixed order: deterministic, no atomics.  The bias gradient sits
@@ -348,6 +353,8 @@ class SVAEEngine:
             ev = self._tic("wgrad")
             rf, ra = remap if remap is not None else (N if not dy_bf16 else (N + 7) // 8 * 8, 0)
             fn = "svae_wgrad_cols_bf16dy" if dy_bf16 else ("svae_wgrad_cols_prec" if self.split else "svae_wgrad_cols")
+            if x_bf16:
+                fn = "svae_wgrad_cols_bf16dy_bf16x"
             tail = (rf, ra, self.prec, _stream()) if fn == "svae_wgrad_cols_prec" else (rf, ra, _stream())
             if ns == 1:
                 _lib.call(fn, dY.data_ptr(), X.data_ptr(), out, out + 4 * N * K, R, N, K, ldy, ldx, 1, 0, *tail)
@@ -412,11 +419,17 @@ class SVAEEngine:
                                      and want_loss and want_grad and self.gru_prec == PREC_BF16 and plan.split_t > 0)
                     else 0)
         head_fused = self.fused and self.rowgemm and self.prec == PREC_BF16 and self.head_fused
+        # (bf16 rows need the bf16 gradient array on the other side: the weight-gradient kernel's bf16-X form reads both)
+        # (the fused loss paths only: training, whose backward then has the bf16 gradient array, and scoring, which
+        #  has no backward; the dense notebook surface keeps fp32 rows)
+        e16 = (head_fused and self.emb16 and self.gru_prec == PREC_BF16 and self.merged_dg and self.dg_bf16
+               and not self.bptt_split and want_loss)
+        self._emb16_live = bool(e16)
         if head_fused:
             # gather + W_ih fragments in one launch (both head the step, neither needs the other)
             _lib.call("svae_embed_fwd_wih_prep", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
-                      w["emb"].data_ptr(), gi_split if gi_split else R, self.I, self.P("gru.weight_ih_l0").data_ptr(),
-                      self.wih_frags[0].data_ptr(), st)
+                      (w["emb16"] if e16 else w["emb"]).data_ptr(), gi_split if gi_split else R, self.I,
+                      self.P("gru.weight_ih_l0").data_ptr(), self.wih_frags[0].data_ptr(), 1 if e16 else 0, st)
         else:
             _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
                       w["emb"].data_ptr(), gi_split if gi_split else R, self.I, st)
@@ -427,9 +440,13 @@ class SVAEEngine:
                 _lib.call("svae_rowgemm_prep_prec", self.P("gru.weight_ih_l0").data_ptr(), 0,
                           self.wih_frags[0].data_ptr(), self.prec, st)
             ev = self._tic("gi_gemm")
-            _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr(), E, self.wih_frags[0].data_ptr(),
-                      self.P("gru.bias_ih_l0").data_ptr(), w["gi"].data_ptr(), gi_split if gi_split else R, 0,
-                      self.prec, st)
+            if e16:
+                _lib.call("svae_rowgemm_gi_bf16x", w["emb16"].data_ptr(), E, self.wih_frags[0].data_ptr(),
+                          self.P("gru.bias_ih_l0").data_ptr(), w["gi"].data_ptr(), gi_split if gi_split else R, st)
+            else:
+                _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr(), E, self.wih_frags[0].data_ptr(),
+                          self.P("gru.bias_ih_l0").data_ptr(), w["gi"].data_ptr(), gi_split if gi_split else R, 0,
+                          self.prec, st)
             self._toc("gi_gemm", ev)
             if gi_split:
                 head_done = self._sev("head_done")
@@ -477,12 +494,22 @@ class SVAEEngine:
                 if gi_split:
                     # (behind the parameter preparation: the decoder side of the first range waits for that, the
                     #  second recurrence, which needs these rows, only starts when the first one has ended)
-                    _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr() + 4 * gi_split,
-                              w["emb"].data_ptr() + 4 * E * gi_split, R - gi_split, self.I, _stream())
+                    if e16:
+                        _lib.call("svae_embed_fwd_bf16", self.P("item_embed.weight").data_ptr(),
+                                  plan.x.data_ptr() + 4 * gi_split, w["emb16"].data_ptr() + 2 * E * gi_split,
+                                  R - gi_split, self.I, _stream())
+                    else:
+                        _lib.call("svae_embed_fwd", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr() + 4 * gi_split,
+                                  w["emb"].data_ptr() + 4 * E * gi_split, R - gi_split, self.I, _stream())
                     _lib.stream_wait(side, head_done)          # (the W_ih fragments)
-                    _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr() + 4 * E * gi_split, E,
-                              self.wih_frags[0].data_ptr(), self.P("gru.bias_ih_l0").data_ptr(),
-                              w["gi"].data_ptr() + 4 * G * gi_split, R - gi_split, 0, self.prec, _stream())
+                    if e16:
+                        _lib.call("svae_rowgemm_gi_bf16x", w["emb16"].data_ptr() + 2 * E * gi_split, E,
+                                  self.wih_frags[0].data_ptr(), self.P("gru.bias_ih_l0").data_ptr(),
+                                  w["gi"].data_ptr() + 4 * G * gi_split, R - gi_split, _stream())
+                    else:
+                        _lib.call("svae_rowgemm_ld_prec", w["emb"].data_ptr() + 4 * E * gi_split, E,
+                                  self.wih_frags[0].data_ptr(), self.P("gru.bias_ih_l0").data_ptr(),
+                                  w["gi"].data_ptr() + 4 * G * gi_split, R - gi_split, 0, self.prec, _stream())
                 if t1 > 0:
                     _lib.stream_wait(side, first_done)
                     gru_range(t1, plan.Tmax, "gru_fwd2")
@@ -956,7 +983,12 @@ class SVAEEngine:
             # kernel trace shows the caller's queue busy 898 of a step's 971 us -- it is the critical path, and by the
             # end of the BPTT the side stream has been idle for ~70 us.)
             self._wgrad(dgh, w["hprev"], "gru.weight_hh_l0", R, G, HP, ldg, HP, remap=hh_remap, dy_bf16=dg16)
-            self._wgrad(dgi, w["emb"], "gru.weight_ih_l0", R, G, E, ldg, E, dy_bf16=dg16)
+            if self._emb16_live:
+                if not dg16:
+                    raise ValueError("bf16 embedding rows need the bf16 gradient array (forward with want_grad)")
+                self._wgrad(dgi, w["emb16"], "gru.weight_ih_l0", R, G, E, ldg, E, dy_bf16=True, x_bf16=True)
+            else:
+                self._wgrad(dgi, w["emb"], "gru.weight_ih_l0", R, G, E, ldg, E, dy_bf16=dg16)
 
         if tb:
             self._tail_two_ranges(plan, cur, side, late_done, dgi, ldg, rb, hh_remap)

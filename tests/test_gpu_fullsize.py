@@ -226,8 +226,9 @@ def test_fused_operand_copies_equal_the_two_kernel_path():
 def test_step_order_options_leave_the_step_bit_identical():
     """The late scheduling moves of round 2 change where and when kernels run, not what they compute: the gather and
     the W_ih fragments in one launch (svae_embed_fwd_wih_prep) against the two kernels, and the second time range's
-    MLP chain on the side stream against the caller's -- loss, every gradient and the parameters after the optimizer
-    step are bit-identical, over three train steps of an ML-20M-shaped batch with a time split."""
+    MLP chain on the side stream against the caller's, and the gathered embedding rows kept as bf16 (their consumers
+    round them to bf16 anyway) against fp32 rows -- loss, every gradient and the parameters after the optimizer step
+    are bit-identical, over three train steps of an ML-20M-shaped batch with a time split."""
     import svae_cf_amd as S
     from svae_cf_amd import synth
     I, B = 20000, 256
@@ -241,19 +242,25 @@ def test_step_order_options_leave_the_step_bit_identical():
             break
     assert plan is not None
     got = {}
-    for tag, head, mlp2 in (("old", False, False), ("new", True, True)):
+    for tag, head, mlp2, e16 in (("old", False, False, False), ("new", True, True, False), ("emb16", True, True, True)):
         eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
         _init(eng, 5)
-        eng.head_fused, eng.mlp2_side = head, mlp2
+        eng.head_fused, eng.mlp2_side, eng.emb16 = head, mlp2, e16
         eng.prepare(plan)
         losses = []
         for s in range(3):
             losses.append(eng.train_step(plan, 0.05, seed=9, step=s).clone())
         torch.cuda.synchronize()
         got[tag] = dict(losses=torch.stack(losses), grads=eng.grads.clone(), params=eng.params.clone(),
-                        frags=eng.wih_frags[0].clone(), emb=eng.ws["emb"][:plan.R * 256].clone())
-    for k in got["old"]:
-        assert torch.equal(got["old"][k], got["new"][k]), k
+                        frags=eng.wih_frags[0].clone())
+        if e16:      # the bf16 rows are the fp32 rows of the other runs, rounded to nearest even
+            emb16 = eng.ws["emb16"][:plan.R * 256].clone()
+        else:
+            got[tag]["emb"] = eng.ws["emb"][:plan.R * 256].clone()
+    for tag in ("new", "emb16"):
+        for k in got[tag]:
+            assert torch.equal(got["old"][k], got[tag][k]), (tag, k)
+    assert torch.equal(emb16, got["old"]["emb"].to(torch.bfloat16))
 
 
 def test_two_range_bptt_equals_one_launch():
