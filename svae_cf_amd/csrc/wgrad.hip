@@ -79,9 +79,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     if (bz >= a.nz) return;
     const int bx = mem % a.nx, by = mem / a.nx;
     const int m0 = by * WM, n0 = bx * WN;
-    const int ntiles = (a.R + WK - 1) / WK;
-    const int t_begin = bz * a.tiles_per_split;
-    int t_end = t_begin + a.tiles_per_split;
+    // Rows per stage.  With both operands bf16 a stage of 32 rows costs the LDS of a 16-row fp32 stage and the k-loop
+    // (one wait, one barrier, fragment builds and 4 MFMAs per wave and 16 rows) makes half as many trips -- measured:
+    // no difference (dW_ih 19.5 us either way), like halving the X bytes before it (-1.6 us) and quartering the LDS
+    // instructions in round 2: none of the three is what bounds this kernel.  Kept, harmless.
+    // a.tiles_per_split counts 16-row tiles; the splits' row boundaries are the same multiples of 32 rows in every
+    // instantiation (wgrad_launch), so all of them add the same rows into the same slabs.
+    constexpr int WKT = XBF ? 32 : WK;
+    const int ntiles = (a.R + WKT - 1) / WKT;
+    const int tps = a.tiles_per_split / (WKT / WK);
+    const int t_begin = bz * tps;
+    int t_end = t_begin + tps;
     if (t_end > ntiles) t_end = ntiles;
 
     const __amdgpu_buffer_rsrc_t dyb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((size_t)a.R * a.ldy * (ABF ? 2 : 4)), BUF_FLAGS);
@@ -99,7 +107,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const unsigned r0_ = (unsigned)(t_) * WK + 2 * wave + rowl;                                             \
         if (ABF) {                                                                                             \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)l_, 16,      \
-                                                     ((unsigned)(t_) * WK + 4 * wave + rowa) * (unsigned)a.ldy * 2u + colA, 0, 0, 0); \
+                                                     ((unsigned)(t_) * WKT + 4 * wave + rowa) * (unsigned)a.ldy * 2u + colA, 0, 0, 0); \
+            if (XBF)                                                                                           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)(l_ + 4096), 16, \
+                                                         ((unsigned)(t_) * WKT + 16 + 4 * wave + rowa) * (unsigned)a.ldy * 2u + colA, 0, 0, 0); \
         } else {                                                                                               \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dyb, (__attribute__((address_space(3))) void*)l_, 16,      \
                                                      r0_ * (unsigned)a.ldy * 4u + colA, 0, 0, 0);               \
@@ -108,7 +119,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }                                                                                                      \
         if (XBF) {                                                                                             \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES), 16, \
-                                                     ((unsigned)(t_) * WK + 4 * wave + rowa) * (unsigned)a.ldx * 2u + colB, 0, 0, 0); \
+                                                     ((unsigned)(t_) * WKT + 4 * wave + rowa) * (unsigned)a.ldx * 2u + colB, 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES + 4096), 16, \
+                                                     ((unsigned)(t_) * WKT + 16 + 4 * wave + rowa) * (unsigned)a.ldx * 2u + colB, 0, 0, 0); \
         } else {                                                                                               \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xb, (__attribute__((address_space(3))) void*)(l_ + TILE_BYTES), 16, \
                                                      r0_ * (unsigned)a.ldx * 4u + colB, 0, 0, 0);               \
@@ -137,14 +150,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int st = (t - t_begin) & (NST - 1);
         // own pieces of tile t landed (tiles t+1, t+2 may still be in flight: 8 younger pieces)
         // (pieces per tile and wave: 2 + 2, or 1 + 2 with a bf16 dY)
-        // (pieces per tile and wave: 2 + 2; 1 + 2 with a bf16 dY; 1 + 1 with a bf16 X as well)
+        // (pieces per tile and wave: 2 + 2; 1 + 2 with a bf16 dY; 2 + 2 again with both bf16 and 32-row stages)
         if (t + 2 < t_end) {
-            if (XBF) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (ABF) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (ABF && !XBF) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else if (t + 1 < t_end) {
-            if (XBF) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (ABF) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if (ABF && !XBF) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -157,15 +168,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const unsigned short* sAh = reinterpret_cast<const unsigned short*>(sA);
         if (do_cs) {
 #pragma unroll
-            for (int k = 0; k < WK; ++k) cs += ABF ? sv_bf2f(sAh[k * WM + tid]) : sA[k * WM + tid];
+            for (int k = 0; k < WKT; ++k) cs += ABF ? sv_bf2f(sAh[k * WM + tid]) : sA[k * WM + tid];
         }
+#pragma unroll
+        for (int ks = 0; ks < WKT / WK; ++ks) {       // one MFMA k-step = 16 rows of the stage
         // fragment of a 32-column group: lane (li, lh) takes rows 8 lh .. 8 lh + 7 of column base + li
         bf16x8 fa[2], fb[2], fam[2], fbm[2], fal[2], fbl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             uint4 u;
             if (ABF) {
-                const unsigned short* p = sAh + (8 * lh) * WM + wm + 32 * i + li;
+                const unsigned short* p = sAh + (16 * ks + 8 * lh) * WM + wm + 32 * i + li;
                 u.x = (unsigned)p[0] | ((unsigned)p[WM] << 16); u.y = (unsigned)p[2 * WM] | ((unsigned)p[3 * WM] << 16);
                 u.z = (unsigned)p[4 * WM] | ((unsigned)p[5 * WM] << 16); u.w = (unsigned)p[6 * WM] | ((unsigned)p[7 * WM] << 16);
                 fa[i] = __builtin_bit_cast(bf16x8, u);
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         for (int j = 0; j < 2; ++j) {
             const float* p = sB + (8 * lh) * WN + wn + 32 * j + li;
             if (XBF) {
-                const unsigned short* q = reinterpret_cast<const unsigned short*>(sB) + (8 * lh) * WN + wn + 32 * j + li;
+                const unsigned short* q = reinterpret_cast<const unsigned short*>(sB) + (16 * ks + 8 * lh) * WN + wn + 32 * j + li;
                 uint4 u;
                 u.x = (unsigned)q[0] | ((unsigned)q[WN] << 16); u.y = (unsigned)q[2 * WN] | ((unsigned)q[3 * WN] << 16);
                 u.z = (unsigned)q[4 * WN] | ((unsigned)q[5 * WN] << 16); u.w = (unsigned)q[6 * WN] | ((unsigned)q[7 * WN] << 16);
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
+        }
     }
 #undef SV_WG_STAGE
 
@@ -295,8 +309,9 @@ static int wgrad_launch(const void* dy_, int dy_bf16, const float* x, float* out
                  "svae_wgrad: operand larger than a 4 GiB buffer descriptor");
     WgradArgs a{dy, x, out, colsum, R, N, K, ldy, ldx, (K + WN - 1) / WN, (N + WM - 1) / WM, nsplit, 0, slab_stride,
                 remap_from, remap_add};
-    const int ntiles = (R + WK - 1) / WK;
-    a.tiles_per_split = (ntiles + nsplit - 1) / nsplit;
+    // a split = a whole number of 32-row stages (the same row boundaries for the 16- and the 32-row instantiations)
+    const int n32 = (R + 31) / 32;
+    a.tiles_per_split = 2 * ((n32 + nsplit - 1) / nsplit);
     const int gsize = a.nx * a.ny;
     static bool attr_done = false;
     if (!attr_done) {
