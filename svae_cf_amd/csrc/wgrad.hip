@@ -8,7 +8,15 @@
 // three tiles in flight per block; a wave builds its bf16 fragments from the row-major tile with conflict-free
 // column reads (lanes = consecutive columns) -- no staging registers, no transposing stores.
 //
-// What bounds it now (round 2, rocprofv3 + a rewrite that did not pay): a form of the bf16-dY kernel with both
+// What bounds it (late round 2, tools/probe/wgrad_time.py with the two SV_WG_EXP builds below, dW_ih alone at 21.8k
+// rows, 30.7 us per back-to-back launch): with every fragment taken by ONE lane-linear 16-byte LDS read instead of
+// eight 2-byte column reads (SV_WG_EXP=1: wrong values, same instruction mix otherwise) 23.3 us; with no tile staged
+// after the prologue (SV_WG_EXP=2) 29.3 us.  So the column gathers are a quarter of the kernel -- 64 LDS
+// instructions per wave and 16 rows, eight waves on a CU -- and the operand bytes from L2 are not the bound; the
+// rest is the k-loop's per-stage latency and the slab stores.  The fix is a transposing read of a swizzled bf16
+// image (ds_read_b64_tr_b16 as in proj.hip: 2 reads per fragment); the round-2 attempt at that (below) kept
+// row-major, unswizzled images whose rows all start on bank 0, which is the likely reason it gained nothing.
+// Earlier notes (round 2, rocprofv3 + a rewrite that did not pay): a form of the bf16-dY kernel with both
 // operands staged as bf16 images and fragments from ds_read_b64_tr_b16 -- 16 LDS reads per 8 MFMAs instead of 64 reads
 // and 32 packs -- ran in the same 24 us (dW_ih, 24k rows).  The kernel moves bytes, not fragments: with 128 x 128
 // output tiles dY is read twice and X six times, 64 + 147 MB from L2 per launch, 8.8 TB/s in those 24 us, plus the
@@ -162,7 +170,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();       // tile t complete; everyone is done reading tile t-1's stage
         asm volatile("" ::: "memory");
+#if !defined(SV_WG_EXP) || SV_WG_EXP != 2
         if (t + NST - 1 < t_end) SV_WG_STAGE(t + NST - 1, (st + NST - 1) & (NST - 1))
+#endif
         const float* sA = reinterpret_cast<const float*>(smem + st * STAGE_BYTES);
         const float* sB = sA + WK * WM;
         const unsigned short* sAh = reinterpret_cast<const unsigned short*>(sA);
@@ -177,6 +187,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             uint4 u;
+#if defined(SV_WG_EXP) && SV_WG_EXP == 1
+            if (true) { u = *reinterpret_cast<const uint4*>(sAh + 8 * lane + 512 * i + 1024 * ks); fa[i] = __builtin_bit_cast(bf16x8, u); } else
+#endif
             if (ABF) {
                 const unsigned short* p = sAh + (16 * ks + 8 * lh) * WM + wm + 32 * i + li;
                 u.x = (unsigned)p[0] | ((unsigned)p[WM] << 16); u.y = (unsigned)p[2 * WM] | ((unsigned)p[3 * WM] << 16);
@@ -196,6 +209,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float* p = sB + (8 * lh) * WN + wn + 32 * j + li;
+#if defined(SV_WG_EXP) && SV_WG_EXP == 1
+            if (true) { const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(sB) + 8 * lane + 512 * j + 1024 * ks); fb[j] = __builtin_bit_cast(bf16x8, u); } else
+#endif
             if (XBF) {
                 const unsigned short* q = reinterpret_cast<const unsigned short*>(sB) + (16 * ks + 8 * lh) * WN + wn + 32 * j + li;
                 uint4 u;
