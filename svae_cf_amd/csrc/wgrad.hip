@@ -48,6 +48,29 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
+// A bf16 operand tile in LDS is [rows][128 columns] with 256-byte rows whose 16-byte chunks are XOR-swizzled by the
+// row: chunk ch of row r sits at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))).  The LDS-DMA that fills it is
+// lane-linear, so the swizzle is applied on the GLOBAL side (a lane fetches the chunk that belongs at its LDS
+// position); the four rows of a transposing read then fall into the four 64-byte quarters of the bank row and a
+// 32-lane half (two 4 x 16 blocks side by side) is conflict-free.  Unswizzled, all rows start on bank 0: 4-way.
+__device__ __forceinline__ unsigned swz_off(unsigned row, unsigned ch) {
+    return 256u * row + 16u * (ch ^ (((row & 3u) << 2) | ((row >> 2) & 3u)));
+}
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, lane 4q + p supplies the address
+// of row q, columns 4p .. 4p + 3, lane i receives column i of the four rows.  EXEC is full at every call below.
+__device__ __forceinline__ s4v tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)p);
+}
+// byte offset (inside a swizzled tile, k-step 0) this lane supplies for half h (rows 8 (g >> 1) + 4 h + q) of the
+// fragment of the 32-column group that starts at column cb: two such reads are the lane's 8 k-values of column
+// cb + (lane & 31), in the MFMA's own order.
+__device__ __forceinline__ unsigned tr_lane_off(int lane, int cb, int h) {
+    const unsigned g = (unsigned)lane >> 4, q = ((unsigned)lane >> 2) & 3u, pp = (unsigned)lane & 3u;
+    return swz_off(8u * (g >> 1) + 4u * (unsigned)h + q, (unsigned)cb / 8u + 2u * (g & 1u) + (pp >> 1)) + 8u * (pp & 1u);
+}
+
 // ABF: dY holds bf16 elements (the GRU's merged gradient array): its tile is 16 rows x 128 columns x 2 B = 4 KiB, one
 // LDS-DMA piece (4 rows) per wave, and a fragment is built from 2-byte reads without conversion.
 // hi / mid / lo parts of 8 fp32 values as three bf16 fragments: hi = RNE(v), mid = RNE(v - hi), lo = RNE(v - hi - mid);
@@ -105,10 +128,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     // one piece = one wave-instruction = 2 tile rows x 128 columns; a tile is 8 pieces per operand, wave w
     // issues pieces w and w + 4 of both.  Columns beyond the operand's width fall into the next row (finite
     // garbage that only reaches output rows / columns that are never stored) or beyond the buffer (zeros).
-    const int ca = ABF ? m0 + 8 * (lane & 15) : m0 + 4 * (lane & 31);
-    const unsigned colA = (unsigned)(ca + (ca >= a.remap_from ? a.remap_add : 0)) * (ABF ? 2u : 4u), colB = XBF ? (unsigned)(n0 + 8 * (lane & 15)) * 2u : (unsigned)(n0 + 4 * (lane & 31)) * 4u;
     const unsigned rowl = (unsigned)(lane >> 5);
     const unsigned rowa = (unsigned)(lane >> 4);      // ABF: row of the lane inside its 4-row piece
+    // bf16 tiles: the lane's tile row is 4 wave + rowa (+ 16), so its swizzle term is (rowa << 2) | wave (swz_off)
+    // (the all-bf16 form only: with an fp32 X beside it the transposing reads of dY alone made the kernel SLOWER,
+    // 30.7 -> 33.8 us for dW_ih at 21.8k rows, so the mixed form keeps its row-major image and 2-byte column reads)
+    constexpr bool TR = XBF;
+    const int chs = (lane & 15) ^ (int)((rowa << 2) | (unsigned)wave);
+    const int ca = ABF ? m0 + 8 * (TR ? chs : (lane & 15)) : m0 + 4 * (lane & 31);
+    const unsigned colA = (unsigned)(ca + (ca >= a.remap_from ? a.remap_add : 0)) * (ABF ? 2u : 4u), colB = XBF ? (unsigned)(n0 + 8 * chs) * 2u : (unsigned)(n0 + 4 * (lane & 31)) * 4u;
 #define SV_WG_STAGE(t_, st_)                                                                                   \
     {                                                                                                          \
         char* l_ = smem + (st_) * STAGE_BYTES + wave * 1024;                                                    \
@@ -138,6 +166,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }                                                                                                      \
     }
 
+    unsigned trA[2][2], trB[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            trA[i][h] = tr_lane_off(lane, wm + 32 * i, h);
+            trB[i][h] = tr_lane_off(lane, wn + 32 * i, h);
+        }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -175,10 +211,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #endif
         const float* sA = reinterpret_cast<const float*>(smem + st * STAGE_BYTES);
         const float* sB = sA + WK * WM;
-        const unsigned short* sAh = reinterpret_cast<const unsigned short*>(sA);
         if (do_cs) {
 #pragma unroll
-            for (int k = 0; k < WKT; ++k) cs += ABF ? sv_bf2f(sAh[k * WM + tid]) : sA[k * WM + tid];
+            for (int k = 0; k < WKT; ++k)
+                cs += TR ? sv_bf2f(*reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(sA) + swz_off((unsigned)k, (unsigned)tid >> 3) + 2u * ((unsigned)tid & 7u)))
+                          : ABF ? sv_bf2f(reinterpret_cast<const unsigned short*>(sA)[k * WM + tid]) : sA[k * WM + tid];
         }
 #pragma unroll
         for (int ks = 0; ks < WKT / WK; ++ks) {       // one MFMA k-step = 16 rows of the stage
@@ -187,11 +224,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             uint4 u;
-#if defined(SV_WG_EXP) && SV_WG_EXP == 1
-            if (true) { u = *reinterpret_cast<const uint4*>(sAh + 8 * lane + 512 * i + 1024 * ks); fa[i] = __builtin_bit_cast(bf16x8, u); } else
-#endif
-            if (ABF) {
-                const unsigned short* p = sAh + (16 * ks + 8 * lh) * WM + wm + 32 * i + li;
+            if (TR) {        // two transposing reads of the swizzled image (k-step ks = 16 rows = 4096 bytes further)
+                const char* tA = reinterpret_cast<const char*>(sA) + 4096 * ks;
+                fa[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr16(tA + trA[i][0]), tr16(tA + trA[i][1]), 0, 1, 2, 3, 4, 5, 6, 7));
+            } else if (ABF) {
+                const unsigned short* p = reinterpret_cast<const unsigned short*>(sA) + (16 * ks + 8 * lh) * WM + wm + 32 * i + li;
                 u.x = (unsigned)p[0] | ((unsigned)p[WM] << 16); u.y = (unsigned)p[2 * WM] | ((unsigned)p[3 * WM] << 16);
                 u.z = (unsigned)p[4 * WM] | ((unsigned)p[5 * WM] << 16); u.w = (unsigned)p[6 * WM] | ((unsigned)p[7 * WM] << 16);
                 fa[i] = __builtin_bit_cast(bf16x8, u);
@@ -209,15 +246,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float* p = sB + (8 * lh) * WN + wn + 32 * j + li;
-#if defined(SV_WG_EXP) && SV_WG_EXP == 1
-            if (true) { const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(sB) + 8 * lane + 512 * j + 1024 * ks); fb[j] = __builtin_bit_cast(bf16x8, u); } else
-#endif
             if (XBF) {
-                const unsigned short* q = reinterpret_cast<const unsigned short*>(sB) + (16 * ks + 8 * lh) * WN + wn + 32 * j + li;
-                uint4 u;
-                u.x = (unsigned)q[0] | ((unsigned)q[WN] << 16); u.y = (unsigned)q[2 * WN] | ((unsigned)q[3 * WN] << 16);
-                u.z = (unsigned)q[4 * WN] | ((unsigned)q[5 * WN] << 16); u.w = (unsigned)q[6 * WN] | ((unsigned)q[7 * WN] << 16);
-                fb[j] = __builtin_bit_cast(bf16x8, u);
+                const char* tB = reinterpret_cast<const char*>(sB) + 4096 * ks;
+                fb[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tr16(tB + trB[j][0]), tr16(tB + trB[j][1]), 0, 1, 2, 3, 4, 5, 6, 7));
             } else if (SPLIT) {
                 const float v[8] = {p[0], p[WN], p[2 * WN], p[3 * WN], p[4 * WN], p[5 * WN], p[6 * WN], p[7 * WN]};
                 split8(v, fb[j], fbm[j], fbl[j]);

@@ -1,0 +1,96 @@
+"""The weight-gradient GEMM entry points of the C-ABI on their own (csrc/wgrad.hip): gW[N][K] = dY^T X and gb = column
+sums of dY, the autograd of y = x W^T + b inside loss.backward() (nb:1205), in every operand form the step uses --
+fp32 operands rounded on the fly, the split (fp32-class) instantiation, bf16 dY (the GRU's merged gate-gradient
+array, with the column remap of the recurrent weights) and bf16 dY with bf16 X (swizzled LDS images read with
+ds_read_b64_tr_b16).  Checked against a float64 product of the operands as the kernel sees them (bf16-rounded for the
+bf16 forms): the only difference left is the fp32 accumulation order, gate 2e-6 relative to the largest entry (the
+exact integer case is bit-exact and catches any misplaced row, column or k index).  Ragged row counts (1, a partial
+stage, several splits with a partial last split) and widths that are not multiples of the 128-column tiles."""
+import numpy as np
+import pytest
+import torch
+
+from svae_cf_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fn, dy, x, R, N, K, ldy, ldx, ns, remap, prec=None):
+    dev = dy.device
+    stride = N * K + N
+    slabs = torch.full((ns * stride,), float("nan"), device=dev)
+    out = torch.empty(stride, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    sp = slabs.data_ptr()
+    tail = (remap[0], remap[1], st) if prec is None else (remap[0], remap[1], prec, st)
+    _lib.call(fn, dy.data_ptr(), x.data_ptr(), sp, sp + 4 * N * K, R, N, K, ldy, ldx, ns, stride, *tail)
+    _lib.call("svae_reduce_slabs", sp, out.data_ptr(), stride, ns, stride, st)
+    torch.cuda.synchronize()
+    return out[: N * K].view(N, K).cpu().numpy(), out[N * K:].cpu().numpy()
+
+
+def _ref(dy, x, R, N, K, remap):
+    cols = np.arange(N)
+    cols = cols + np.where(cols >= remap[0], remap[1], 0)
+    d = dy[:R].double().cpu().numpy()[:, cols]
+    xx = x[:R, :K].double().cpu().numpy()
+    return d.T @ xx, d.sum(0)
+
+
+CASES = [
+    # R, N, K, ldy, ldx, nsplit, remap
+    (1, 672, 256, 896, 256, 1, (672, 0)),
+    (37, 672, 256, 896, 256, 1, (672, 0)),
+    (1000, 672, 224, 896, 224, 5, (448, 224)),
+    (4099, 672, 256, 896, 256, 32, (672, 0)),
+    (2500, 200, 72, 208, 72, 7, (200, 0)),
+]
+
+
+@pytest.mark.parametrize("form", ["fp32", "split", "bf16dy", "bf16dy_bf16x"])
+@pytest.mark.parametrize("case", CASES)
+def test_wgrad_forms_against_float64(form, case):
+    R, N, K, ldy, ldx, ns, remap = case
+    g = torch.Generator(device="cuda").manual_seed(R * 7 + N)
+    dy = torch.randn(R + 3, ldy, device="cuda", generator=g) * 0.1
+    x = torch.randn(R + 3, ldx, device="cuda", generator=g)
+    if form == "fp32":
+        got = _run("svae_wgrad_cols", dy, x, R, N, K, ldy, ldx, ns, remap)
+        # the bias gradient sums dY as stored (fp32); only the MFMA operands are rounded
+        ref = (_ref(dy.bfloat16(), x.bfloat16(), R, N, K, remap)[0], _ref(dy, x, R, N, K, remap)[1])
+    elif form == "split":
+        got = _run("svae_wgrad_cols_prec", dy, x, R, N, K, ldy, ldx, ns, remap, prec=2)
+        ref = _ref(dy, x, R, N, K, remap)
+    elif form == "bf16dy":
+        d16 = dy.bfloat16()
+        got = _run("svae_wgrad_cols_bf16dy", d16, x, R, N, K, ldy, ldx, ns, remap)
+        ref = _ref(d16, x.bfloat16(), R, N, K, remap)
+    else:
+        if ldx % 8 or remap[0] % 8 or remap[1] % 8:
+            pytest.skip("the all-bf16 form takes multiples of 8 columns")
+        d16, x16 = dy.bfloat16(), x.bfloat16()
+        got = _run("svae_wgrad_cols_bf16dy_bf16x", d16, x16, R, N, K, ldy, ldx, ns, remap)
+        ref = _ref(d16, x16, R, N, K, remap)
+    tol = 2e-6 if form != "split" else 1e-6
+    for a, b, name in ((got[0], ref[0], "gW"), (got[1], ref[1], "gb")):
+        assert np.isfinite(a).all(), (form, name)
+        assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-30) * max(1.0, np.sqrt(R) / 8), (form, name, np.abs(a - b).max(), np.abs(b).max())
+
+
+@pytest.mark.parametrize("form", ["fp32", "bf16dy", "bf16dy_bf16x"])
+def test_wgrad_small_integers_are_exact(form):
+    """Operands are small integers (exact in bf16, sums exact in fp32): any misplaced row, column or k index shows as
+    a wrong integer.  Asymmetric data, R not a multiple of the stage."""
+    R, N, K, ldy, ldx, ns, remap = 333, 672, 224, 896, 224, 3, (448, 224)
+    r = torch.arange(R + 1, device="cuda").view(-1, 1)
+    dy = ((r * 3 + torch.arange(ldy, device="cuda") * 5) % 7 - 3).float()
+    x = ((r * 5 + torch.arange(ldx, device="cuda") * 11) % 5 - 2).float()
+    if form == "fp32":
+        got = _run("svae_wgrad_cols", dy, x, R, N, K, ldy, ldx, ns, remap)
+    elif form == "bf16dy":
+        got = _run("svae_wgrad_cols_bf16dy", dy.bfloat16(), x, R, N, K, ldy, ldx, ns, remap)
+    else:
+        got = _run("svae_wgrad_cols_bf16dy_bf16x", dy.bfloat16(), x.bfloat16(), R, N, K, ldy, ldx, ns, remap)
+    ref = _ref(dy, x, R, N, K, remap)
+    assert np.array_equal(got[0], ref[0].astype(np.float32))
+    assert np.array_equal(got[1], ref[1].astype(np.float32))
