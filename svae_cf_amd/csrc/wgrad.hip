@@ -8,19 +8,18 @@
 // three tiles in flight per block; a wave builds its bf16 fragments from the row-major tile with conflict-free
 // column reads (lanes = consecutive columns) -- no staging registers, no transposing stores.
 //
-// What bounds it (late round 2, tools/probe/wgrad_time.py with the two SV_WG_EXP builds below, dW_ih alone at 21.8k
-// rows, 30.7 us per back-to-back launch): with every fragment taken by ONE lane-linear 16-byte LDS read instead of
-// eight 2-byte column reads (SV_WG_EXP=1: wrong values, same instruction mix otherwise) 23.3 us; with no tile staged
-// after the prologue (SV_WG_EXP=2) 29.3 us.  So the column gathers are a quarter of the kernel -- 64 LDS
-// instructions per wave and 16 rows, eight waves on a CU -- and the operand bytes from L2 are not the bound; the
-// rest is the k-loop's per-stage latency and the slab stores.  The fix is a transposing read of a swizzled bf16
-// image (ds_read_b64_tr_b16 as in proj.hip: 2 reads per fragment); the round-2 attempt at that (below) kept
-// row-major, unswizzled images whose rows all start on bank 0, which is the likely reason it gained nothing.
-// Earlier notes (round 2, rocprofv3 + a rewrite that did not pay): a form of the bf16-dY kernel with both
-// operands staged as bf16 images and fragments from ds_read_b64_tr_b16 -- 16 LDS reads per 8 MFMAs instead of 64 reads
-// and 32 packs -- ran in the same 24 us (dW_ih, 24k rows).  The kernel moves bytes, not fragments: with 128 x 128
-// output tiles dY is read twice and X six times, 64 + 147 MB from L2 per launch, 8.8 TB/s in those 24 us, plus the
-// 2 x 22 MB of the slabs.  The next step would be fewer re-reads (256 x 128 tiles, bf16 copies of X), not a faster loop.
+// The all-bf16 form (bf16 dY and bf16 X: the GRU's input-weight gradient) keeps both tiles as XOR-swizzled bf16 images
+// and takes a fragment with two ds_read_b64_tr_b16 (swz_off / tr_lane_off below): 16 LDS instructions per wave and
+// 32 rows instead of 128 two-byte reads and their packing.  dW_ih alone at 21.8k rows, back-to-back launches
+// (tools/probe/wgrad_time.py): 30.6 -> 24.1 us, which is what an experiment build with one lane-linear 16-byte read
+// per fragment (wrong values, same instruction mix otherwise) had given as the bound of this change (23.3 us).  Inside
+// the step the kernel's region did not move (A/B of the whole step: 0.8756 ms both): it runs beside the weight
+// sweep's finish kernels and the optimizer, and what they contend for is not its LDS reads.
+// What did not carry over: (1) the same reads for dY alone with an fp32 X beside it (the mixed form, dW_hh) made that
+// kernel slower, 30.7 -> 33.8 us, so it keeps row-major images and column reads; (2) the first attempt at transposing
+// reads in round 2 used row-major, unswizzled images whose rows all start on bank 0 (4-way conflicts on every read)
+// and gained nothing.  With no tile staged after the prologue (SV_WG_EXP=2) the old kernel ran 29.3 us of its 30.7:
+// the operand bytes from L2 are not the bound either; the rest is the k-loop's per-stage latency and the slab stores.
 #include "common.h"
 
 namespace {

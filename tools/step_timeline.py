@@ -6,7 +6,9 @@ f = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 mainq = collections.Counter(r['Queue_Id'] for r in rows if 'gru_bwd' in r['Kernel_Name']).most_common(1)[0][0]
-starts = [i for i, r in enumerate(rows) if 'embed_fwd_kernel' in r['Kernel_Name'] and r['Queue_Id'] == mainq]
+# a step begins with the head of the forward on the main queue: the fused gather (embed_wih_prep) or the plain one
+head = 'embed_wih_prep_kernel' if any('embed_wih_prep_kernel' in r['Kernel_Name'] for r in rows) else 'embed_fwd_kernel'
+starts = [i for i, r in enumerate(rows) if head in r['Kernel_Name'] and r['Queue_Id'] == mainq]
 starts = starts[len(starts) // 3:]
 spans = sorted((int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp']), a, b) for a, b in zip(starts[:-1], starts[1:]))
 pick = spans[len(spans) // 2] if len(sys.argv) < 3 else spans[int(float(sys.argv[2]) * (len(spans) - 1))]
