@@ -944,7 +944,11 @@ class SVAEEngine:
                 decoder_side_wgrads(self.slabs_side)
                 if self._loss_deferred:
                     # last on this stream: a one-workgroup kernel that waited 40 us for a free CU beside the sweep
-                    # when it came first, with the weight gradients queued behind it
+                    # when it came first, with the weight gradients queued behind it.  (Later still -- behind the
+                    # side stream's join point, the caller's stream waiting for it only at the end of train_step, so
+                    # that it no longer sits in front of the GRU weight gradients -- measured 0.7 % SLOWER, 0.8728 vs
+                    # 0.8666 ms per step over three alternating pairs (tools/ab_env.sh): a kernel trace, where this
+                    # kernel shows as 8 - 25 us on the chain into the optimizer, is no guide to the untraced step.)
                     _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(),
                               plan.w_nll.data_ptr(), plan.w_kl.data_ptr(), float(anneal), R,
                               self.loss_out.data_ptr(), _stream())
