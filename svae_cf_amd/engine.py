@@ -98,7 +98,9 @@ class SVAEEngine:
         self.loss_out = torch.zeros(4, **f32)
         self.cap = 0
         self.ws = {}
-        self.nsplit = int(os.environ.get("SVAE_NSPLIT", "32"))   # row splits of the weight-gradient GEMMs
+        # row splits of the weight-gradient GEMMs (end of round 2, tools/sweep_env.sh, ms per step on one box, two
+        # rounds: 32 -> 0.868 / 0.870, 16 -> 0.867 / 0.870, 24 -> 0.868 / 0.869, 21 -> 0.881 / 0.879, 48 -> 0.883 / 0.881)
+        self.nsplit = int(os.environ.get("SVAE_NSPLIT", "32"))
         self.slabs = torch.zeros(self.nsplit * (G * E + G), **f32)        # largest split-K output: dW_ih
         self.slabs_side = torch.zeros(self.nsplit * (DP * HP + DP), **f32)  # side-stream weight gradients
         self.slabs_hh = None                 # (two-range BPTT: dW_hh's slabs stay pending beside dW_ih's)
