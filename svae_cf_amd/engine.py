@@ -143,6 +143,9 @@ class SVAEEngine:
         self.gru_wgrad_side = os.environ.get("SVAE_GRU_WGRAD_SIDE", "1") == "1"
         self.gi_split = os.environ.get("SVAE_GI_SPLIT", "1") == "1"
         self.bptt_split = os.environ.get("SVAE_BPTT_SPLIT", "0") == "1"
+        # (both split counts re-swept on the round's final step, tools/sweep_env.sh, ms per step on one box, two rounds:
+        #  forward 3 -> 0.864, 4 -> 0.864, 5 -> 0.870, 6 -> 0.872, 8 -> 0.883; weight gradient 2 -> 0.866, 3 -> 0.924,
+        #  4 -> 0.911)
         self.fdh_q0 = int(os.environ.get("SVAE_FDH_Q0", "4"))  # nominal split count of the forward sweep (_proj_sched)
         self._sevs = {}                # purpose -> _lib.SyncEvent, re-recorded every step
         self._sched_cache = {}         # tile-count shape -> (device table, nwg, ns_q, ns_rem), see _proj_sched
