@@ -969,6 +969,10 @@ __global__ void proj_fdh_finish_kernel(const float* __restrict__ slabs, const fl
     if (row >= R) return;
     const int ln = lane < KP / 4 ? lane : 0;
     const int ns = ns_q + ((row / BX) < ns_rem ? 1 : 0);     // wave-uniform
+    // everything that depends on the row number only goes out first (K == 4: the targets in one 16-byte load)
+    const int4 t4 = K == 4 ? *reinterpret_cast<const int4*>(tgt + (size_t)row * 4) : make_int4(-1, -1, -1, -1);
+    const float w = w_nll[row];
+    const float4 hv = reinterpret_cast<const float4*>(h2 + (size_t)row * KP)[ln];
     float ms[NS_MAX];
     float M = NEG_BIG;
 #pragma unroll
@@ -995,11 +999,32 @@ __global__ void proj_fdh_finish_kernel(const float* __restrict__ slabs, const fl
     const float l = __shfl(u.w, C_MH / 4, 64);            // column 155 = sum of P
     const float lse2 = M + log2f(l);
     const float lse = lse2 * LN2;
-    const float w = w_nll[row];
-    const float4 hv = reinterpret_cast<const float4*>(h2 + (size_t)row * KP)[ln];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float nll = 0.f;
     int nr = 0;
+    if (K == 4) {
+        // next_k = 4 (every configuration of the reference): straight-line code, so that the row's targets, its h2 row
+        // and weight go out with the slab loads above and the four W3 rows one round trip behind them.  The general
+        // loop below is a chain of dependent loads (target -> W3 row -> reduce, four times, behind the slabs), and at
+        // 8 waves per SIMD and 2.7 rounds of workgroups that chain WAS the kernel: 24 us for 60 MB.  Same operations
+        // in the same order: bit-identical.
+        const float4 wv[4] = {reinterpret_cast<const float4*>(w3 + (size_t)(t4.x < 0 ? 0 : t4.x) * KP)[ln],
+                              reinterpret_cast<const float4*>(w3 + (size_t)(t4.y < 0 ? 0 : t4.y) * KP)[ln],
+                              reinterpret_cast<const float4*>(w3 + (size_t)(t4.z < 0 ? 0 : t4.z) * KP)[ln],
+                              reinterpret_cast<const float4*>(w3 + (size_t)(t4.w < 0 ? 0 : t4.w) * KP)[ln]};
+        const float bb[4] = {b3[t4.x < 0 ? 0 : t4.x], b3[t4.y < 0 ? 0 : t4.y], b3[t4.z < 0 ? 0 : t4.z], b3[t4.w < 0 ? 0 : t4.w]};
+        const int its[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float d = lane < KP / 4 ? hv.x * wv[k].x + hv.y * wv[k].y + hv.z * wv[k].z + hv.w * wv[k].w : 0.f;   // pads are zero
+            d = sv_wave_sum(d) + bb[k];
+            if (its[k] >= 0) {
+                nll += lse - d;
+                ++nr;
+                acc.x += wv[k].x; acc.y += wv[k].y; acc.z += wv[k].z; acc.w += wv[k].w;
+            }
+        }
+    } else
     for (int k = 0; k < K; ++k) {
         const int it = tgt[(size_t)row * K + k];     // wave-uniform
         if (it < 0) continue;
