@@ -230,6 +230,17 @@ int svae_embed_fwd_bf16(const float* table, const int* x, void* out16, int R, in
 int svae_rowgemm_gi_bf16x(const void* x16, int ldx, const void* frags, const float* bias, float* y, int R, void* stream);
 int svae_wgrad_cols_bf16dy_bf16x(const void* dy16, const void* x16, float* out, float* colsum, int R, int N, int K, int ldy,
                                  int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream);
+/* The GRU's recurrent- and input-weight gradients (two of the products inside loss.backward(), nb:1205) in ONE launch:
+ * job 0 = svae_wgrad_cols_bf16dy(dy, x0, ...), job 1 = svae_wgrad_cols_bf16dy(dy, x1, ...) or, x1_bf16 != 0,
+ * svae_wgrad_cols_bf16dy_bf16x(dy, x1, ...); both share dy, R, N, ldy and nsplit and write the slabs the single
+ * launches write (bit-identical).  svae_reduce_slabs_pair sums both slab sets in one launch. */
+int svae_wgrad_pair_bf16dy(const void* dy, int R, int N, int ldy, int nsplit,
+                           const float* x0, int K0, int ldx0, float* out0, float* colsum0, long long stride0,
+                           int remap_from0, int remap_add0,
+                           const void* x1, int x1_bf16, int K1, int ldx1, float* out1, float* colsum1, long long stride1,
+                           int remap_from1, int remap_add1, void* stream);
+int svae_reduce_slabs_pair(const float* slabs0, float* out0, long long n0, long long stride0, const float* slabs1,
+                           float* out1, long long n1, long long stride1, int nsplit, void* stream);
 int svae_rowgemm_ld_prec(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,
                          int prec, void* stream);
 int svae_mlp_prep_prec(const float* w1, const float* wl, const float* w2, void* frags, int prec, void* stream);

@@ -94,17 +94,18 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
 // XBF: X holds bf16 elements as well (the embedding rows as the gather wrote them: its consumers round to bf16 anyway,
 // RNE there as here, so the gradient is bit-identical): the X tile is 4 KiB, one piece per wave, and the six
 // re-reads of X from L2 that bound this kernel (header) are half the bytes.
+// bid = the workgroup's index inside its job (the kernel's blockIdx.x, or that minus the first job's workgroups -- a
+// multiple of 8, so that id % 8 stays the XCD -- in the two-job launch below)
 template <bool ABF, bool SPLIT = false, bool XBF = false>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bid, char* smem) {
     static_assert(!(ABF && SPLIT), "the split instantiation reads fp32 operands");
     static_assert(!XBF || ABF, "bf16 X comes with the bf16 dY");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     // blocks of one row split sit on one XCD (id % 8), see gemm.hip
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     const int gsize = a.nx * a.ny, bz = xcd + 8 * (slot / gsize), mem = slot % gsize;
     if (bz >= a.nz) return;
     const int bx = mem % a.nx, by = mem / a.nx;
@@ -292,6 +293,46 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+template <bool ABF, bool SPLIT = false, bool XBF = false>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_body<ABF, SPLIT, XBF>(a, blockIdx.x, smem);
+}
+
+// Two jobs in one launch -- the GRU's recurrent- and input-weight gradients, which share dY and follow each other on
+// the step's tail: job 0 (bf16 dY, fp32 X) on workgroups [0, n0), job 1 (bf16 dY, X fp32 or bf16) on the rest.  One
+// kernel boundary and one slab reduce less on that chain, and no second partial round of workgroups in between;
+// every workgroup does exactly what it does in the single-job launches (same slabs, bit-identical).
+template <bool XBF1>
+__global__ __launch_bounds__(256) void wgrad_pair_kernel(WgradArgs a0, WgradArgs a1, int n0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < n0) wgrad_body<true, false, false>(a0, blockIdx.x, smem);
+    else wgrad_body<true, false, XBF1>(a1, (int)blockIdx.x - n0, smem);
+}
+
+// out_j[i] = sum over job j's slabs, both jobs in one launch (blocks [0, b0): job 0); 8 slabs in flight, fixed order
+__global__ void reduce_slabs_pair_kernel(const float* __restrict__ s0, float* __restrict__ o0, long long n40,
+                                         long long stride0, const float* __restrict__ s1, float* __restrict__ o1,
+                                         long long n41, long long stride1, int nsplit, int b0) {
+    const bool first = (int)blockIdx.x < b0;
+    const float* __restrict__ slabs = first ? s0 : s1;
+    float* __restrict__ out = first ? o0 : o1;
+    const long long n4 = first ? n40 : n41, stride = first ? stride0 : stride1;
+    const int nb = first ? b0 : (int)gridDim.x - b0, b = first ? (int)blockIdx.x : (int)blockIdx.x - b0;
+    for (long long i = (long long)b * blockDim.x + threadIdx.x; i < n4; i += (long long)nb * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z0 = 0; z0 < nsplit; z0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const float4*>(slabs + (z0 + j < nsplit ? z0 + j : 0) * stride)[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (z0 + j < nsplit) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
 }  // namespace
 
 // Reference interface replaced: the weight / bias gradient of one nn.Linear (or of the GRU's input / recurrent
@@ -340,8 +381,9 @@ extern "C" int svae_wgrad_cols_bf16dy(const void* dy, const float* x, float* out
     return wgrad_launch(dy, 1, x, out, colsum, R, N, K, ldy, ldx, nsplit, slab_stride, remap_from, remap_add, stream);
 }
 
-static int wgrad_launch(const void* dy_, int dy_bf16, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
-                        int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream) {
+static int wgrad_args(const void* dy_, const float* x, float* out, float* colsum, int R, int N, int K, int ldy, int ldx,
+                      int nsplit, long long slab_stride, int remap_from, int remap_add, WgradArgs& a, int& gsize) {
+
     const float* dy = (const float*)dy_;
     SV_CHECK_ARG(dy && x && out, "svae_wgrad: null pointer");
     SV_CHECK_ARG(remap_from >= 0 && remap_add >= 0 && (remap_from % 4) == 0 && (remap_add % 4) == 0 && N + remap_add <= ldy,
@@ -349,18 +391,23 @@ static int wgrad_launch(const void* dy_, int dy_bf16, const float* x, float* out
     SV_CHECK_ARG(R > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && (ldy % 4) == 0 && (ldx % 4) == 0,
                  "svae_wgrad: bad shape R=%d N=%d K=%d ldy=%d ldx=%d", R, N, K, ldy, ldx);
     SV_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0, "svae_wgrad: operands must be 16-byte aligned");
-    (void)dy_bf16;   // the 4 GiB limit below is checked for the wider (fp32) element
+    // (the 4 GiB limit below is checked for the wider, fp32, element)
     SV_CHECK_ARG(nsplit >= 1 && (nsplit == 1 || slab_stride >= (long long)N * K), "svae_wgrad: bad split");
     SV_CHECK_ARG((long long)R * ldy * 4 < (1ll << 32) && (long long)R * ldx * 4 < (1ll << 32),
                  "svae_wgrad: operand larger than a 4 GiB buffer descriptor");
-    WgradArgs a{dy, x, out, colsum, R, N, K, ldy, ldx, (K + WN - 1) / WN, (N + WM - 1) / WM, nsplit, 0, slab_stride,
-                remap_from, remap_add};
+    a = WgradArgs{dy, x, out, colsum, R, N, K, ldy, ldx, (K + WN - 1) / WN, (N + WM - 1) / WM, nsplit, 0, slab_stride,
+                  remap_from, remap_add};
     // a split = a whole number of 32-row stages (the same row boundaries for the 16- and the 32-row instantiations)
     const int n32 = (R + 31) / 32;
     a.tiles_per_split = 2 * ((n32 + nsplit - 1) / nsplit);
-    const int gsize = a.nx * a.ny;
+    gsize = a.nx * a.ny;
+    return 0;
+}
+
+static int wgrad_attrs() {
     static bool attr_done = false;
     if (!attr_done) {
+
         hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
@@ -368,9 +415,22 @@ static int wgrad_launch(const void* dy_, int dy_bf16, const float* x, float* out
             e = hipFuncSetAttribute((const void*)wgrad_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)wgrad_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)wgrad_pair_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)wgrad_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
         if (e != hipSuccess) return svae_fail((int)e, "svae_wgrad: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
+    return 0;
+}
+
+static int wgrad_launch(const void* dy_, int dy_bf16, const float* x, float* out, float* colsum, int R, int N, int K, int ldy,
+                        int ldx, int nsplit, long long slab_stride, int remap_from, int remap_add, void* stream) {
+    WgradArgs a;
+    int gsize;
+    if (int rc = wgrad_args(dy_, x, out, colsum, R, N, K, ldy, ldx, nsplit, slab_stride, remap_from, remap_add, a, gsize)) return rc;
+    if (int rc = wgrad_attrs()) return rc;
     if (dy_bf16 == 3)
         hipLaunchKernelGGL((wgrad_kernel<true, false, true>), dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
                            (hipStream_t)stream, a);
@@ -383,6 +443,51 @@ static int wgrad_launch(const void* dy_, int dy_bf16, const float* x, float* out
     else
         hipLaunchKernelGGL(wgrad_kernel<false>, dim3(8 * ((nsplit + 7) / 8) * gsize), dim3(256), NST * STAGE_BYTES,
                            (hipStream_t)stream, a);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// No single counterpart in the reference: the weight gradients of the GRU's recurrent and input weights (two of the
+// matrix products inside loss.backward(), nb:1205) in ONE launch.  Job 0 = svae_wgrad_cols_bf16dy(dy, x0, ...), job 1 =
+// svae_wgrad_cols_bf16dy(dy, x1, ...) or, with x1_bf16 != 0, svae_wgrad_cols_bf16dy_bf16x(dy, x1, ...): the same
+// workgroups writing the same slabs (bit-identical to the two single launches); both jobs share dy, R, N, ldy, nsplit.
+extern "C" int svae_wgrad_pair_bf16dy(const void* dy, int R, int N, int ldy, int nsplit,
+                                      const float* x0, int K0, int ldx0, float* out0, float* colsum0, long long stride0,
+                                      int remap_from0, int remap_add0,
+                                      const void* x1, int x1_bf16, int K1, int ldx1, float* out1, float* colsum1,
+                                      long long stride1, int remap_from1, int remap_add1, void* stream) {
+    SV_CHECK_ARG((ldy % 8) == 0 && (remap_from0 % 8) == 0 && (remap_add0 % 8) == 0 && (remap_from1 % 8) == 0 &&
+                     (remap_add1 % 8) == 0 && (!x1_bf16 || (ldx1 % 8) == 0),
+                 "svae_wgrad_pair_bf16dy: bad alignment");
+    WgradArgs a0, a1;
+    int g0, g1;
+    if (int rc = wgrad_args(dy, x0, out0, colsum0, R, N, K0, ldy, ldx0, nsplit, stride0, remap_from0, remap_add0, a0, g0)) return rc;
+    if (int rc = wgrad_args(dy, (const float*)x1, out1, colsum1, R, N, K1, ldy, ldx1, nsplit, stride1, remap_from1, remap_add1, a1, g1)) return rc;
+    if (int rc = wgrad_attrs()) return rc;
+    const int n0 = 8 * ((nsplit + 7) / 8) * g0, n1 = 8 * ((nsplit + 7) / 8) * g1;     // n0 % 8 == 0: id % 8 stays the XCD
+    if (x1_bf16)
+        hipLaunchKernelGGL(wgrad_pair_kernel<true>, dim3(n0 + n1), dim3(256), NST * STAGE_BYTES, (hipStream_t)stream, a0, a1, n0);
+    else
+        hipLaunchKernelGGL(wgrad_pair_kernel<false>, dim3(n0 + n1), dim3(256), NST * STAGE_BYTES, (hipStream_t)stream, a0, a1, n0);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// svae_reduce_slabs for two slab sets in one launch: out_j[0 .. n_j) = sum_z slabs_j[z * stride_j + i], fixed order.
+extern "C" int svae_reduce_slabs_pair(const float* slabs0, float* out0, long long n0, long long stride0,
+                                      const float* slabs1, float* out1, long long n1, long long stride1, int nsplit,
+                                      void* stream) {
+    SV_CHECK_ARG(slabs0 && out0 && slabs1 && out1 && n0 > 0 && n1 > 0 && (n0 % 4) == 0 && (n1 % 4) == 0 && nsplit >= 1 &&
+                     (stride0 % 4) == 0 && (stride1 % 4) == 0,
+                 "svae_reduce_slabs_pair: bad arguments");
+    SV_CHECK_ARG(((uintptr_t)slabs0 % 16) == 0 && ((uintptr_t)slabs1 % 16) == 0 && ((uintptr_t)out0 % 16) == 0 &&
+                     ((uintptr_t)out1 % 16) == 0, "svae_reduce_slabs_pair: 16-byte alignment");
+    const long long n40 = n0 / 4, n41 = n1 / 4;
+    int b0 = (int)((n40 + 255) / 256), b1 = (int)((n41 + 255) / 256);
+    if (b0 > 1024) b0 = 1024;
+    if (b1 > 1024) b1 = 1024;
+    hipLaunchKernelGGL(reduce_slabs_pair_kernel, dim3(b0 + b1), dim3(256), 0, (hipStream_t)stream, slabs0, out0, n40, stride0,
+                       slabs1, out1, n41, stride1, nsplit, b0);
     SV_LAUNCH_CHECK();
     return 0;
 }

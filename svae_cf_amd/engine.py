@@ -103,7 +103,9 @@ class SVAEEngine:
         self.nsplit = int(os.environ.get("SVAE_NSPLIT", "32"))
         self.slabs = torch.zeros(self.nsplit * (G * E + G), **f32)        # largest split-K output: dW_ih
         self.slabs_side = torch.zeros(self.nsplit * (DP * HP + DP), **f32)  # side-stream weight gradients
-        self.slabs_hh = None                 # (two-range BPTT: dW_hh's slabs stay pending beside dW_ih's)
+        # dW_hh's own slabs: the paired launch of the two GRU weight gradients (and the two-range BPTT) keep them
+        # pending beside dW_ih's
+        self.slabs_hh = torch.zeros(self.nsplit * (G * HP + G), **f32)
         self.dh_carry = None
         # Backward runs on two streams: the data-gradient chain that leads to the GRU's BPTT (a 16-64 CU kernel,
         # latency bound) stays on the caller's stream, the decoder-side weight gradients (whole-GPU kernels that
@@ -124,6 +126,7 @@ class SVAEEngine:
         self._prepped_grad = False
         self._dtmp_extra = None
         self._loss_deferred = False
+        self.wgrad_pair = os.environ.get("SVAE_WGRAD_PAIR", "1") == "1"   # the two GRU weight gradients in one launch
         self.time_split = os.environ.get("SVAE_TIME_SPLIT", "1") == "1"
         self.rowgemm = os.environ.get("SVAE_ROWGEMM", "1") == "1"
         self.merged_dg = os.environ.get("SVAE_MERGED_DG", "1") == "1"
@@ -991,6 +994,23 @@ class SVAEEngine:
             # step.  Round 2: on the existing side stream, behind the dense-layer gradients, +1.4 %, 0.925 -> 0.911 ms: a
             # kernel trace shows the caller's queue busy 898 of a step's 971 us -- it is the critical path, and by the
             # end of the BPTT the side stream has been idle for ~70 us.)
+            ns = max(1, min(self.nsplit, (R + 127) // 128))
+            if self.wgrad_pair and dg16 and self.fused and ns > 1:
+                # both in ONE launch and their slabs summed by ONE reduce (svae_wgrad_pair_bf16dy): the same workgroups
+                # writing the same slabs, one kernel boundary and one reduce less on the tail's side chain
+                e16 = bool(self._emb16_live)
+                xi = w["emb16"] if e16 else w["emb"]
+                o_hh = self._gbase + 4 * self.layout.offset("gru.weight_hh_l0")
+                o_ih = self._gbase + 4 * self.layout.offset("gru.weight_ih_l0")
+                s_hh, s_ih = self.slabs_hh.data_ptr(), self.slabs.data_ptr()
+                st_hh, st_ih = G * HP + G, G * E + G
+                ev = self._tic("wgrad")
+                _lib.call("svae_wgrad_pair_bf16dy", dgi.data_ptr(), R, G, ldg, ns,
+                          w["hprev"].data_ptr(), HP, HP, s_hh, s_hh + 4 * G * HP, st_hh, hh_remap[0], hh_remap[1],
+                          xi.data_ptr(), int(e16), E, E, s_ih, s_ih + 4 * G * E, st_ih, (G + 7) // 8 * 8, 0, _stream())
+                _lib.call("svae_reduce_slabs_pair", s_hh, o_hh, st_hh, st_hh, s_ih, o_ih, st_ih, st_ih, ns, _stream())
+                self._toc("wgrad", ev)
+                return
             self._wgrad(dgh, w["hprev"], "gru.weight_hh_l0", R, G, HP, ldg, HP, remap=hh_remap, dy_bf16=dg16)
             if self._emb16_live:
                 if not dg16:

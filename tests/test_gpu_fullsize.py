@@ -242,10 +242,12 @@ def test_step_order_options_leave_the_step_bit_identical():
             break
     assert plan is not None
     got = {}
-    for tag, head, mlp2, e16 in (("old", False, False, False), ("new", True, True, False), ("emb16", True, True, True)):
+    for tag, head, mlp2, e16, pair in (("old", False, False, False, False), ("new", True, True, False, True),
+                                       ("emb16", True, True, True, True), ("emb16_single", True, True, True, False)):
         eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
         _init(eng, 5)
         eng.head_fused, eng.mlp2_side, eng.emb16 = head, mlp2, e16
+        eng.wgrad_pair = pair      # the two GRU weight gradients in one launch (svae_wgrad_pair_bf16dy) or in two
         eng.prepare(plan)
         losses = []
         for s in range(3):
@@ -253,11 +255,11 @@ def test_step_order_options_leave_the_step_bit_identical():
         torch.cuda.synchronize()
         got[tag] = dict(losses=torch.stack(losses), grads=eng.grads.clone(), params=eng.params.clone(),
                         frags=eng.wih_frags[0].clone())
-        if e16:      # the bf16 rows are the fp32 rows of the other runs, rounded to nearest even
+        if e16 and pair:      # the bf16 rows are the fp32 rows of the other runs, rounded to nearest even
             emb16 = eng.ws["emb16"][:plan.R * 256].clone()
-        else:
+        elif not e16:
             got[tag]["emb"] = eng.ws["emb"][:plan.R * 256].clone()
-    for tag in ("new", "emb16"):
+    for tag in ("new", "emb16", "emb16_single"):
         for k in got[tag]:
             assert torch.equal(got["old"][k], got[tag][k]), (tag, k)
     assert torch.equal(emb16, got["old"]["emb"].to(torch.bfloat16))

@@ -94,3 +94,32 @@ def test_wgrad_small_integers_are_exact(form):
     ref = _ref(dy, x, R, N, K, remap)
     assert np.array_equal(got[0], ref[0].astype(np.float32))
     assert np.array_equal(got[1], ref[1].astype(np.float32))
+
+
+@pytest.mark.parametrize("x1_bf16", [0, 1])
+@pytest.mark.parametrize("R,ns", [(333, 3), (4099, 32)])
+def test_wgrad_pair_equals_the_two_single_launches(x1_bf16, R, ns):
+    """svae_wgrad_pair_bf16dy + svae_reduce_slabs_pair (the GRU's two weight gradients in one launch) against
+    svae_wgrad_cols_bf16dy / _bf16x + svae_reduce_slabs: the same workgroups write the same slabs -- bit-identical."""
+    N, ldy, K0, K1 = 672, 896, 224, 256
+    g = torch.Generator(device="cuda").manual_seed(R)
+    dy = (torch.randn(R + 3, ldy, device="cuda", generator=g) * 0.1).bfloat16()
+    x0 = torch.randn(R + 3, K0, device="cuda", generator=g)
+    x1 = torch.randn(R + 3, K1, device="cuda", generator=g)
+    x1u = x1.bfloat16() if x1_bf16 else x1
+    r0, r1 = (448, 224), (672, 0)
+    a = _run("svae_wgrad_cols_bf16dy", dy, x0, R, N, K0, ldy, K0, ns, r0)
+    b = _run("svae_wgrad_cols_bf16dy_bf16x" if x1_bf16 else "svae_wgrad_cols_bf16dy", dy, x1u, R, N, K1, ldy, K1, ns, r1)
+    st0, st1 = N * K0 + N, N * K1 + N
+    s0 = torch.full((ns * st0,), float("nan"), device="cuda")
+    s1 = torch.full((ns * st1,), float("nan"), device="cuda")
+    o0, o1 = torch.empty(st0, device="cuda"), torch.empty(st1, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("svae_wgrad_pair_bf16dy", dy.data_ptr(), R, N, ldy, ns,
+              x0.data_ptr(), K0, K0, s0.data_ptr(), s0.data_ptr() + 4 * N * K0, st0, r0[0], r0[1],
+              x1u.data_ptr(), x1_bf16, K1, K1, s1.data_ptr(), s1.data_ptr() + 4 * N * K1, st1, r1[0], r1[1], st)
+    _lib.call("svae_reduce_slabs_pair", s0.data_ptr(), o0.data_ptr(), st0, st0, s1.data_ptr(), o1.data_ptr(), st1, st1, ns, st)
+    torch.cuda.synchronize()
+    o0, o1 = o0.cpu().numpy(), o1.cpu().numpy()
+    assert np.array_equal(o0[: N * K0].reshape(N, K0), a[0]) and np.array_equal(o0[N * K0:], a[1])
+    assert np.array_equal(o1[: N * K1].reshape(N, K1), b[0]) and np.array_equal(o1[N * K1:], b[1])
