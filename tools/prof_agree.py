@@ -24,7 +24,7 @@ def trace_ms(*subs):
 
 pairs = [("proj_fdh_fused", ("proj_kernel<1>", "proj_kernel<1,")), ("proj_dw_fused", ("proj_kernel<2>", "proj_kernel<2,")),
          ("gru_fwd", ("gru_fwd_bf16_kernel",)), ("gru_bwd", ("gru_bwd_bf16_kernel",)),
-         ("wgrad", ("wgrad_kernel",)), ("gi_gemm", ("rowgemm_kernel<0",)), ("demb_gemm", ("rowgemm_kernel<1",)),
+         ("wgrad", ("wgrad_kernel", "wgrad_pair_kernel")), ("gi_gemm", ("rowgemm_kernel<0",)), ("demb_gemm", ("rowgemm_kernel<1",)),
          ("mlp_fwd", ("mlp_fwd_kernel",)), ("mlp_bwd", ("mlp_bwd_kernel",))]
 calls = {}
 for r in rows:
