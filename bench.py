@@ -116,6 +116,8 @@ def main():
 
     prec = S.PREC_BF16 if args.prec == "bf16" else S.PREC_FP32
     eng = S.SVAEEngine(I, device=dev, prec=prec)
+    # the loop's stream, as train_batched picks it (high priority unless SVAE_TRAIN_HIPRIO=0)
+    torch.cuda.set_stream(eng.training_stream())
     torch.manual_seed(0)
     sd = {}
     for name, shp in eng.layout.ref_shapes.items():
@@ -404,6 +406,7 @@ def main():
                                    "length-bucketed batch %d users/GPU, next_k=4, fwd+bwd+allreduce+Adam"
                                    % (shape_name, shape_cfg, I, lmax, B),
                        "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "mean_rows_bracketed_steps": rows_timed, "parallelism": "dp%d" % world, "embedding_gradient_exchange": ("rows" if (eng.grad_sync is not None and eng.grad_sync.sparse is not None) else "dense"),
+                       "caller_stream": ("high priority (SVAEEngine.training_stream, as train_batched)" if os.environ.get("SVAE_TRAIN_HIPRIO", "1") == "1" else "default"),
                        "decoder_linear2_exchange": ("reduce-scatter + sharded optimizer + all-gather" if (eng.grad_sync is not None and eng.grad_sync.sharded is not None) else "all-reduce"),
                        "final_loss": loss, "side_stream": eng.side_stream_info},
             "kernel_ms": kt, "kernel_timing": "HIP events on the launch streams over a replay of the first %d timed steps "

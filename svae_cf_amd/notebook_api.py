@@ -467,12 +467,18 @@ def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, 
         eng.reserve(max(int(lens_all[np.asarray(b)].sum()) - len(b) for b in batches))   # rows = sum of (length - 1)
     plans = PlanPrefetcher(batches, csr[1], k, eng.device, total_items=eng.I, prepare=eng.prepare,
                            workers=workers, depth=4 * workers)
-    for b, (idx, plan) in enumerate(zip(batches, plans), start=1):
-        anneal = users_anneal(users_before) if anneal_by == "users" else anneal_for_batch(b)
-        eng.train_step(plan, anneal, seed=seed + epoch)
-        users_before += len(idx) * world
-        if log is not None and b % max(1, hyper_params["batch_log_interval"] // batch_size) == 0:
-            log("| epoch {:3d} | {:5d}/{:5d} batches | loss {:5.4f}".format(epoch, b, len(batches), float(eng.loss_out[0])))
+    # the loop runs on the engine's high-priority stream (SVAEEngine.training_stream): the caller's chain of a step is
+    # its critical path and shares the GPU with the engine's own side streams
+    outer, hi = torch.cuda.current_stream(), eng.training_stream()
+    hi.wait_stream(outer)
+    with torch.cuda.stream(hi):
+        for b, (idx, plan) in enumerate(zip(batches, plans), start=1):
+            anneal = users_anneal(users_before) if anneal_by == "users" else anneal_for_batch(b)
+            eng.train_step(plan, anneal, seed=seed + epoch)
+            users_before += len(idx) * world
+            if log is not None and b % max(1, hyper_params["batch_log_interval"] // batch_size) == 0:
+                log("| epoch {:3d} | {:5d}/{:5d} batches | loss {:5.4f}".format(epoch, b, len(batches), float(eng.loss_out[0])))
+    outer.wait_stream(hi)
     train_batched.last_wait_s = plans.wait_s          # (diagnostic: time the loop spent waiting for plans)
     return len(batches)
 
