@@ -18,20 +18,30 @@
 
 namespace {
 
-constexpr int RG_ROWS = 128;      // rows per workgroup (4 waves x 32)
+// Waves per workgroup (32 rows each).  dL/demb runs 8 waves = 256 rows per workgroup: half as many workgroups (228 at
+// 21.8k rows: one round of the GPU instead of 1.8), half the L2 -> LDS traffic of the weight fragments, two waves per
+// SIMD -- its region in the step 105 -> 98 us, the step itself within the spread (0.8694 -> 0.8682 and 0.8635 -> 0.8626 ms,
+// two A/Bs of three alternating pairs, end of round 2);
+// bit-identical (a row's arithmetic does not depend on its workgroup).  The split instantiation stays at 4 waves (at
+// 8 it needs more than the 256 registers two waves per SIMD leave it), and so does the gi GEMM (its three column
+// chunks of 8 tiles already make one round).
+#ifndef SV_RG1_NW
+#define SV_RG1_NW 8
+#endif
 
 // CT = n-tiles (of 32 columns) per column chunk, chosen so that ALL fragments of a chunk (CT x K/16 KiB) fit the LDS;
 // XG = k-steps per group of row loads, PDX = groups in flight ahead of the one being multiplied.
 template <int WHICH> struct RgShape;
-template <> struct RgShape<0> { static constexpr int K = SV_E, N = SV_G, CT = 8, XG = 4, PDX = 3; };
-template <> struct RgShape<1> { static constexpr int K = SV_G, N = SV_E, CT = 3, XG = 6, PDX = 2; };
+template <> struct RgShape<0> { static constexpr int K = SV_E, N = SV_G, CT = 8, XG = 4, PDX = 3, NW = 4; };
+template <> struct RgShape<1> { static constexpr int K = SV_G, N = SV_E, CT = 3, XG = 6, PDX = 2, NW = SV_RG1_NW; };
+template <int WHICH, bool SPLIT> constexpr int rg_nw() { return SPLIT ? 4 : RgShape<WHICH>::NW; }
 
 struct RgArgs {
     const float* x;               // [R][K]
     const unsigned short* frags;  // weight fragments, consumption order (rowgemm_prep)
     const float* bias;            // [N] or nullptr
     float* y;                     // [R][N]
-    int R, nrb;                   // rows, row blocks of 128
+    int R, nrb;                   // rows, row blocks of 32 NW
     int ldx;                      // row stride of x (floats, >= K)
     const unsigned short* frags_lo;   // SPLIT: the mid parts of the weight, same fragment order, followed (K*N elements
                                       // further) by the lo parts; read from L2, not staged
@@ -68,7 +78,7 @@ __device__ __forceinline__ void rg_glds16(const char* g, char* l) {
 // parts (24 bits), a product as the six leading terms (rows split in registers, the weight's mid / lo fragments read
 // straight from L2: the LDS is full of the hi fragments).
 template <int WHICH, bool XB, bool SPLIT = false>
-__global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
+__global__ __launch_bounds__((64 * rg_nw<WHICH, SPLIT>())) void rowgemm_kernel(RgArgs a) {
     static_assert(!(XB && SPLIT), "the split instantiation reads fp32 rows");
     using S = RgShape<WHICH>;
     constexpr int K = S::K, N = S::N, CT = S::CT, XG = S::XG, PDX = S::PDX;
@@ -84,7 +94,8 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
     const int c = q % NCH, rb = 8 * (q / NCH) + (id & 7);
     if (rb >= a.nrb) return;                                             // whole workgroup
     const int ntc = (NT - c * CT) < CT ? (NT - c * CT) : CT;
-    const int row = rb * RG_ROWS + wave * 32 + li;
+    constexpr int NW = rg_nw<WHICH, SPLIT>();
+    const int row = rb * (32 * NW) + wave * 32 + li;
     const bool rok = row < a.R;
     const float* xr = XB ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.x) +
                                                            (size_t)(rok ? row : a.R - 1) * a.ldx + 8 * lh)
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RgArgs a) {
     {
         const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)c * CT * KS * 1024 + lane * 16;
         const int npieces = ntc * KS;
-        for (int p = wave; p < npieces; p += 4) rg_glds16(src + (size_t)p * 1024, wst + p * 1024);
+        for (int p = wave; p < npieces; p += NW) rg_glds16(src + (size_t)p * 1024, wst + p * 1024);
     }
     float4 xraw[PDX + 1][XG][XB ? 1 : 2];
 #define RG_LOADX(g_)                                                                                         \
@@ -271,9 +282,10 @@ int rg_launch(RgArgs a, hipStream_t st) {
         if (e != hipSuccess) return svae_fail((int)e, "svae_rowgemm: LDS attribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    a.nrb = (a.R + RG_ROWS - 1) / RG_ROWS;
+    constexpr int NW = rg_nw<WHICH, SPLIT>();
+    a.nrb = (a.R + 32 * NW - 1) / (32 * NW);
     const int groups = (a.nrb + 7) / 8;                 // 8 row blocks (one per XCD) x nch chunks each
-    hipLaunchKernelGGL((rowgemm_kernel<WHICH, XB, SPLIT>), dim3(groups * nch * 8), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((rowgemm_kernel<WHICH, XB, SPLIT>), dim3(groups * nch * 8), dim3(64 * NW), lds, st, a);
     SV_LAUNCH_CHECK();
     return 0;
 }
