@@ -23,8 +23,11 @@ namespace {
 // SIMD -- its region in the step 105 -> 98 us, the step itself within the spread (0.8694 -> 0.8682 and 0.8635 -> 0.8626 ms,
 // two A/Bs of three alternating pairs, end of round 2);
 // bit-identical (a row's arithmetic does not depend on its workgroup).  The split instantiation stays at 4 waves (at
-// 8 it needs more than the 256 registers two waves per SIMD leave it), and so does the gi GEMM (its three column
-// chunks of 8 tiles already make one round).
+// 8 it needs more than the 256 registers two waves per SIMD leave it).  The gi GEMM likewise (126 + 144 workgroups for
+// the two time ranges instead of 252 + 288): its region 33 -> 31 us, the step 0.8696 -> 0.8667 ms, three alternating pairs.
+#ifndef SV_RG0_NW
+#define SV_RG0_NW 8
+#endif
 #ifndef SV_RG1_NW
 #define SV_RG1_NW 8
 #endif
@@ -32,7 +35,7 @@ namespace {
 // CT = n-tiles (of 32 columns) per column chunk, chosen so that ALL fragments of a chunk (CT x K/16 KiB) fit the LDS;
 // XG = k-steps per group of row loads, PDX = groups in flight ahead of the one being multiplied.
 template <int WHICH> struct RgShape;
-template <> struct RgShape<0> { static constexpr int K = SV_E, N = SV_G, CT = 8, XG = 4, PDX = 3, NW = 4; };
+template <> struct RgShape<0> { static constexpr int K = SV_E, N = SV_G, CT = 8, XG = 4, PDX = 3, NW = SV_RG0_NW; };
 template <> struct RgShape<1> { static constexpr int K = SV_G, N = SV_E, CT = 3, XG = 6, PDX = 2, NW = SV_RG1_NW; };
 template <int WHICH, bool SPLIT> constexpr int rg_nw() { return SPLIT ? 4 : RgShape<WHICH>::NW; }
 
