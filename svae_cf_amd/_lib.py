@@ -132,14 +132,7 @@ def load():
 _fns = {}
 
 
-# Timing experiments only (tools/skip_sensitivity.sh): entry points named in SVAE_SKIP are not called, so that the
-# step's sensitivity to each kernel can be read off the step time.  Results are then wrong by construction.
-_SKIP = frozenset(x for x in os.environ.get("SVAE_SKIP", "").split(",") if x)
-
-
 def call(name, *args):
-    if _SKIP and name in _SKIP:
-        return
     fn = _fns.get(name)
     if fn is None:
         fn = _fns[name] = getattr(load(), name)
@@ -147,6 +140,22 @@ def call(name, *args):
     if rc != 0:
         msg = load().svae_last_error().decode("utf-8", "replace")
         raise SvaeHipError("%s failed (rc=%d): %s" % (name, rc, msg))
+
+
+def install_skip(names):
+    """Timing experiments only (tools/skip_sensitivity.sh, tools/bench_skip.py): replaces ``call`` by a variant that
+    leaves the named entry points out, so that the step's sensitivity to each kernel can be read off the step time.
+    Results are then wrong by construction -- the product path never calls this, and no environment variable does."""
+    global call
+    names, real = frozenset(names), call
+
+    def call_skipping(name, *args):
+        if name in names:
+            return None
+        return real(name, *args)
+    import sys
+    sys.stderr.write("svae_cf_amd._lib: SKIPPING %s -- timing experiment, results are wrong\n" % sorted(names))
+    call = call_skipping
 
 
 def proj_schedule(nx, ny, ncu, uniform=False):

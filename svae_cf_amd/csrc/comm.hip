@@ -34,11 +34,18 @@ struct Rccl {
 Rccl g_rccl;
 std::once_flag g_once;
 
+char g_load_error[512] = "(unknown)";   // why the load failed: dlerror() clears itself when read, so it is kept here
+
 void load_rccl() {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    size_t used = 0;
     for (const char* n : names) {
         g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.h) break;
+        const char* e = dlerror();
+        int w = snprintf(g_load_error + used, sizeof(g_load_error) - used, "%s%s: %s", used ? "; " : "", n,
+                         e ? e : "(unknown)");
+        if (w > 0) used = used + (size_t)w < sizeof(g_load_error) ? used + (size_t)w : sizeof(g_load_error) - 1;
     }
     if (!g_rccl.h) return;
     auto sym = [&](const char* s) { return dlsym(g_rccl.h, s); };
@@ -55,7 +62,7 @@ void load_rccl() {
 
 int need_rccl(const char* who) {
     std::call_once(g_once, load_rccl);
-    if (!g_rccl.ok) return svae_fail(-3, "%s: librccl could not be loaded (%s)", who, g_rccl.h ? "symbols missing" : dlerror());
+    if (!g_rccl.ok) return svae_fail(-3, "%s: librccl could not be loaded (%s)", who, g_rccl.h ? "symbols missing" : g_load_error);
     return 0;
 }
 int rc_of(int r, const char* who) {

@@ -135,7 +135,9 @@ class GradSync:
             live = ids >= 0
             # pad entries add zeros (a rank's count is not known on the host, and is not asked for: no sync) -- spread
             # over the table: thousands of atomic adds to ONE row took a millisecond
-            table.index_add_(0, torch.where(live, ids, sp["spread"]), vals * live.unsqueeze(1).to(vals.dtype))
+            # (selected, not multiplied: rows beyond a rank's count keep earlier steps' contents, and 0 * Inf is NaN)
+            table.index_add_(0, torch.where(live, ids, sp["spread"]),
+                             torch.where(live.unsqueeze(1), vals, torch.zeros((), dtype=vals.dtype, device=vals.device)))
 
     def bucket_ready(self, i):
         """Call when every gradient of bucket i has been enqueued on the current stream."""

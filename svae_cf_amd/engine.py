@@ -431,6 +431,13 @@ class SVAEEngine:
                         t.record_stream(s_)
         params_ready = None
         eps_done = False
+        if eps is not None:
+            # the caller's noise goes in FIRST, on the caller's stream and ahead of `step_begin`: the side stream's MLP
+            # chain of the second time range reads w["eps"] and is ordered behind that event only (validated before
+            # anything has been enqueued)
+            if eps.numel() != R * L:
+                raise ValueError("eps must have %d x %d elements" % (R, L))
+            w["eps"][:R * L].copy_(eps.reshape(-1))
         if self.fused and self.overlap:
             side = self._side_stream(cur=cur)
             step_begin = self._sev("step_begin")
@@ -546,11 +553,7 @@ class SVAEEngine:
                         self._decoder_rows(plan, r1, R, self._ncu, sweep=False)
                     second_done = self._sev("second_done")
                     second_done.record(side)
-        if eps is not None:
-            if eps.numel() != R * L:
-                raise ValueError("eps must have %d x %d elements" % (R, L))
-            w["eps"][:R * L].copy_(eps.reshape(-1))
-        elif not eps_done:
+        if eps is None and not eps_done:
             _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
                       int(step) & 0xFFFFFFFF, st)
         if self.fused:

@@ -296,3 +296,40 @@ def test_two_range_bptt_equals_one_launch():
     for k in got[False][1]:
         a, b = got[True][1][k], got[False][1][k]
         assert _l2(a, b) <= 2e-6, (k, _l2(a, b))
+
+
+def test_caller_supplied_noise_on_a_time_split_plan():
+    """`eps` handed in by the caller (parity mode) on a plan with a time split: the second range's MLP chain runs on
+    the side stream and reads the noise buffer, so the caller's noise must be in place before that stream is released
+    (round 2's advisor finding: it was copied in afterwards, on the caller's stream).  Three steps with a DIFFERENT
+    noise array each (a stale buffer would then show), the side-stream MLP on and off: bit-identical losses, gradients
+    and parameters; a wrong-sized array is refused before anything is enqueued."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    I, B = 20000, 256
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(2048, I, mu, sigma, lmax, seed=4321)
+    plan = None
+    for cand in synth.bucketed_batches([len(u) for u in users], B, np.random.default_rng(2)):
+        p = S.build_plan([users[i] for i in cand], 4, user_keys=cand, device="cuda", total_items=I)
+        if p.split_t > 0:
+            plan = p
+            break
+    assert plan is not None
+    g = torch.Generator(device="cuda").manual_seed(3)
+    noise = [torch.randn(plan.R, 64, device="cuda", generator=g) for _ in range(3)]
+    got = {}
+    for side in (False, True):
+        eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+        _init(eng, 5)
+        eng.mlp2_side = side
+        eng.prepare(plan)
+        losses = [eng.train_step(plan, 0.05, eps=noise[s]).clone() for s in range(3)]
+        torch.cuda.synchronize()
+        got[side] = dict(losses=torch.stack(losses), grads=eng.grads.clone(), params=eng.params.clone())
+        with pytest.raises(ValueError):
+            eng.train_step(plan, 0.05, eps=noise[0][:-1])
+        torch.cuda.synchronize()
+        assert torch.equal(eng.params, got[side]["params"]), "a refused call must not have run anything"
+    for k in got[False]:
+        assert torch.equal(got[False][k], got[True][k]), k
