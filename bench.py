@@ -70,6 +70,8 @@ def main():
                     help="decoder.linear2 gradient: reduce-scatter + sharded optimizer + all-gather (auto: >= 100k items)")
     ap.add_argument("--eval-leg", action="store_true", help="also time the scoring leg (forward + masked top-100)")
     ap.add_argument("--no-kernel-times", action="store_true", help="do not bracket kernels with events (no roofline)")
+    ap.add_argument("--no-fp32-class", action="store_true",
+                    help="skip the short leg that times the same step at the reference's own precision (PREC_SPLIT)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions in all: the first is the contractual one (`value`), the others give the spread")
     args = ap.parse_args()
@@ -382,6 +384,37 @@ def main():
                                 achieved=tb / (topk_ms * 1e-3) / 1e9, peak=PEAK["hbm"], unit="GB/s",
                                 frac=tb / (topk_ms * 1e-3) / 1e9 / PEAK["hbm"]))
 
+    # The same step at the REFERENCE's precision (the notebook computes in fp32): PREC_SPLIT runs the timed kernel
+    # templates with every operand as bf16 hi + mid + lo parts (fp32-class results: the parity gates run through this
+    # mode).  A few steps over the same plans, same parameters; reported beside `value`, never as `value`.
+    fp32_class = None
+    if rank == 0 and world == 1 and not rehearse and args.prec == "bf16" and not args.no_fp32_class:
+        torch.cuda.synchronize()
+        eng2 = S.SVAEEngine(I, device=dev, prec=S.PREC_SPLIT)
+        eng2.load_state_dict(sd)
+        eng2.reserve(max(p_.R for p_ in plans))
+        for p_ in plans:
+            eng2.prepare(p_)
+        n2w, n2 = 3, 8
+        for i in range(n2w):
+            eng2.train_step(plans[i % len(plans)], 0.01, seed=1234)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        u2 = 0
+        for i in range(n2):
+            p_ = plans[(n2w + i) % len(plans)]
+            eng2.train_step(p_, 0.01, seed=1234)
+            u2 += p_.B
+        torch.cuda.synchronize()
+        d2 = time.perf_counter() - t0
+        fp32_class = dict(mode="split", value=u2 / d2, unit="sequences/s", ms_per_step=d2 / n2 * 1e3, steps=n2, warmup=n2w,
+                          final_loss=float(eng2.loss_out[0]),
+                          note="PREC_SPLIT: the timed kernel templates with operands as bf16 hi+mid+lo parts and six "
+                               "products per MFMA (fp32-class: loss 1e-5, gradients and parameters 1e-4 against the "
+                               "reference, tests/test_gpu_split_parity.py); the reference itself computes in fp32")
+        del eng2
+        torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import svae_torch as TP           # checker / baseline leg only
@@ -411,7 +444,7 @@ def main():
                        "final_loss": loss, "side_stream": eng.side_stream_info},
             "kernel_ms": kt, "kernel_timing": "HIP events on the launch streams over a replay of the first %d timed steps "
                                              "(events inside the timed region stall the launch pipeline)" % replay_steps, "roofline": roofline, "rooflines": rooflines,
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "fp32_class": fp32_class,
         }
         if ev_leg is not None:
             out["eval_leg"] = ev_leg

@@ -36,6 +36,10 @@ _PINNED_OBJ = [None]
 
 
 _POOL_LOCK = threading.Lock()
+# Streams are created once per process and device and shared by every engine (see SVAEEngine._side_stream):
+_TRAIN_STREAMS = {}      # device index -> the high-priority stream of the training loop
+_STREAM_POOL = {}        # (device index, priority) -> candidate side streams, at most 8
+_SIDE_CHOICE = {}        # (device index, priority, streams to run beside) -> (chosen stream, measurement)
 
 
 def _stream():
@@ -112,6 +116,7 @@ class SVAEEngine:
         # nothing downstream waits for) go to a side stream and fill the CUs the recurrence leaves idle.
         self.overlap = True
         self._sides = []
+        self._sides_by_caller = {}     # caller's stream -> the side streams chosen to run beside it
         self._side_for = None
         self.side_stream_info = []
         self.colparts = torch.zeros(64 * max(self.IP, G), **f32)
@@ -309,32 +314,55 @@ class SVAEEngine:
         return ev
 
     def training_stream(self):
-        """A high-priority stream for the caller's side of the training loop (one per engine).  The engine is
-        stream-agnostic -- a step runs on whatever stream is current -- but the caller's chain is the step's critical
-        path and competes for CUs with the engine's own side streams: at high priority the step measured 0.24 %
-        shorter (0.8497 -> 0.8477 ms, three alternating pairs).  ``SVAE_TRAIN_HIPRIO=0``: the current stream."""
+        """A high-priority stream for the caller's side of the training loop (one per device and process, shared by
+        every engine: streams are a finite resource of the runtime).  The engine is stream-agnostic -- a step runs on
+        whatever stream is current -- but the caller's chain is the step's critical path and competes for CUs with
+        the engine's own side streams: at high priority the step measured 0.24 % shorter (0.8497 -> 0.8477 ms, three
+        alternating pairs).  ``SVAE_TRAIN_HIPRIO=0``: the current stream."""
         if os.environ.get("SVAE_TRAIN_HIPRIO", "1") != "1":
             return torch.cuda.current_stream(self.device)
         if self._train_stream is None:
-            self._train_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            key = self._dev_index()
+            with _POOL_LOCK:
+                if key not in _TRAIN_STREAMS:
+                    _TRAIN_STREAMS[key] = torch.cuda.Stream(device=self.device, priority=-1)
+            self._train_stream = _TRAIN_STREAMS[key]
         return self._train_stream
+
+    def _dev_index(self):
+        return self.device.index if self.device.index is not None else torch.cuda.current_device()
 
     def _side_stream(self, which=0, cur=None):
         """Stream `which` (0, 1) of the overlapped work.  HIP maps streams onto a few hardware queues (4 per
         process here) and two streams that share a queue run IN ORDER: a side stream that landed on the caller's
         queue serialises the whole backward (seen with the process group created before the engine: 1.17 -> 1.54 ms
         per step).  So the streams are chosen by measurement: candidates are tried until one runs a spin kernel
-        concurrently with the caller's stream (and with the side streams chosen before it)."""
+        concurrently with the caller's stream (and with the side streams chosen before it).
+        The choice is kept PER CALLER STREAM (an epoch of train_batched runs on the training stream, evaluate() on the
+        caller's own: switching between them must not choose again), the candidates come from a pool of at most 8
+        streams per device and priority that every engine of the process shares, and what was measured for one
+        engine holds for the next (the mapping of a stream to its queue does not change).  Round 3: before this, every
+        switch of the caller's stream created up to 16 new streams and spun on them; after ~330 switches in one
+        process (tools/convergence.py: 160 epochs, each followed by an evaluation) a spin never completed."""
         cur = torch.cuda.current_stream() if cur is None else cur
         if self._side_for != cur.cuda_stream:
-            self._sides, self._side_for, self.side_stream_info = [], cur.cuda_stream, []
+            self._sides = self._sides_by_caller.setdefault(cur.cuda_stream, [])
+            self._side_for = cur.cuda_stream
         while len(self._sides) <= which:
             self._sides.append(self._pick_concurrent_stream([cur] + self._sides))
         return self._sides[which]
 
     def _pick_concurrent_stream(self, others, tries=8, usec=200):
-        """A new stream that runs concurrently with every stream of `others` (others[0] = the caller's)."""
+        """A stream that runs concurrently with every stream of `others` (others[0] = the caller's)."""
         cur = others[0]
+        prio = self.side_prio[min(len(others) - 1, len(self.side_prio) - 1)]
+        dev = self._dev_index()
+        ckey = (dev, prio, tuple(o.cuda_stream for o in others))
+        with _POOL_LOCK:
+            hit = _SIDE_CHOICE.get(ckey)
+        if hit is not None:
+            self.side_stream_info.append(dict(hit[1], cached=True))
+            return hit[0]
 
         def spin_all(cand):
             torch.cuda.synchronize(self.device)
@@ -349,19 +377,31 @@ class SVAEEngine:
             e1.record(cur)
             e1.synchronize()
             return e0.elapsed_time(e1) * 1e3
-        prio = self.side_prio[min(len(others) - 1, len(self.side_prio) - 1)]
-        cands = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(tries)]
-        times = []
-        for c in cands:
+        with _POOL_LOCK:
+            pool = _STREAM_POOL.setdefault((dev, prio), [])
+        taken = set(o.cuda_stream for o in others)
+        cands, times, choice = [], [], None
+        for i in range(tries):
+            with _POOL_LOCK:
+                if i >= len(pool):
+                    pool.append(torch.cuda.Stream(device=self.device, priority=prio))
+                c = pool[i]
+            if c.cuda_stream in taken:
+                continue
             spin_all(c)                       # first use of a stream creates its queue: not timed
             t = min(spin_all(c), spin_all(c))
+            cands.append(c)
             times.append(t)
             if t < 1.5 * usec:
-                self.side_stream_info.append(dict(tried=len(times), all_us=t, concurrent=True))
-                return c
-        best = min(range(tries), key=lambda i: times[i])
-        self.side_stream_info.append(dict(tried=tries, all_us=times[best], concurrent=False))
-        return cands[best]
+                choice = (c, dict(tried=len(times), all_us=t, concurrent=True))
+                break
+        if choice is None:
+            best = min(range(len(times)), key=lambda i: times[i])
+            choice = (cands[best], dict(tried=len(times), all_us=times[best], concurrent=False))
+        with _POOL_LOCK:
+            _SIDE_CHOICE[ckey] = choice
+        self.side_stream_info.append(choice[1])
+        return choice[0]
 
     def _wgrad(self, dY, X, wname, R, N, K, ldy, ldx, slabs=None, remap=None, dy_bf16=False, x_bf16=False):
         """Weight + bias gradient of y = x W^T + b in one pass: gW[N][K] = dY[R][N]^T X[R][K] and
