@@ -320,6 +320,16 @@ int svae_optimizer_step(int kind, float* p, const float* g, float* a, float* b, 
 int svae_masked_topk(const float* scores, int ld, const int* seen, const int* seen_off, int n_users, int I, int K,
                      int* out_idx, float* out_val, float* work, void* stream);
 
+/* svae_heldout_ranks replaces the hit search of evaluate() nb:636-645 (`argsorted[:k].cpu()`, then `movie in rec_list`
+ * / `rec_list.index(movie)` per held-out item).  topk_idx [n_users][K]: svae_masked_topk's ids, users in the plan's
+ * (length-sorted) order; row_key / last_row: the plan's (the user's global index is row_key[last_row[u]] >> 20);
+ * held / held_off: CSR of the held-out items of ALL n_total_users users of the evaluation, by global index.
+ * rank_out[j] (same indexing as held): 0-based position of held[j] in its user's list, -1 when absent.  Only the
+ * entries of this call's users are written. */
+int svae_heldout_ranks(const int* topk_idx, int n_users, int K, const long long* row_key, const int* last_row,
+                       const int* held, const long long* held_off, long long n_total_users, int* rank_out,
+                       void* stream);
+
 /* No counterpart in the reference.  svae_masked_topk for callers that CANNOT ALLOCATE the `work` buffer: code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernel and results; the scratch is
  * a static device array inside the library (32 MiB per GPU, held until the process ends): n_users * ld <= 8 Mi

@@ -858,6 +858,46 @@ extern "C" int svae_masked_topk(const float* scores, int ld, const int* seen, co
     return 0;
 }
 
+// ---- evaluate()'s membership search ---------------------------------------------------------------------------
+// Reference interface replaced: the hit search of evaluate(), nb:636-645 (`rec_list = argsorted[:k].cpu()`, then
+// `if movie in rec_list` / `rec_list.index(movie)` for every held-out item: an O(n_heldout * k) Python list search per
+// user behind a device-to-host copy).  Here: one workgroup per scored user; the user's top-k ids go to LDS, every held-out
+// item of the user gets its 0-based position in that list, or -1.  The user's GLOBAL index (into held_off) is taken
+// from the noise key of its last row (row_key = user_key << 20 | timestep, svae_plan_create): plans sort their users by
+// length, and the key is what says who is who.  Integer work, bit-exact; the float64 metric arithmetic of nb:637-654
+// stays on the host (one copy of rank_out for the whole evaluation instead of one [users, k] copy per batch).
+__global__ __launch_bounds__(64) void heldout_rank_kernel(const int* __restrict__ idx, int k,
+                                                           const long long* __restrict__ row_key,
+                                                           const int* __restrict__ last_row,
+                                                           const int* __restrict__ held,
+                                                           const long long* __restrict__ held_off, long long n_total_users,
+                                                           int* __restrict__ rank_out) {
+    extern __shared__ int top[];
+    const int u = blockIdx.x;
+    for (int i = threadIdx.x; i < k; i += 64) top[i] = idx[(size_t)u * k + i];
+    __syncthreads();
+    const long long g = row_key[last_row[u]] >> 20;
+    if (g < 0 || g >= n_total_users) return;        // (not a user of this evaluation: the host checks its keys)
+    const long long a = held_off[g], b = held_off[g + 1];
+    for (long long j = a + threadIdx.x; j < b; j += 64) {
+        const int h = held[j];
+        int r = -1;
+        for (int i = 0; i < k; ++i)
+            if (top[i] == h) { r = i; break; }
+        rank_out[j] = r;
+    }
+}
+extern "C" int svae_heldout_ranks(const int* topk_idx, int n_users, int K, const long long* row_key, const int* last_row,
+                                  const int* held, const long long* held_off, long long n_total_users, int* rank_out,
+                                  void* stream) {
+    SV_CHECK_ARG(topk_idx && row_key && last_row && held && held_off && rank_out, "svae_heldout_ranks: null pointer");
+    SV_CHECK_ARG(n_users > 0 && K >= 1 && K <= 4096 && n_total_users >= n_users, "svae_heldout_ranks: bad shape");
+    hipLaunchKernelGGL(heldout_rank_kernel, dim3(n_users), dim3(64), K * sizeof(int), (hipStream_t)stream, topk_idx, K,
+                       row_key, last_row, held, held_off, n_total_users, rank_out);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- the same top-k for callers that cannot allocate (no counterpart in the reference) -----------------------
 // svae_masked_topk takes its scratch copy of the scores (`work`) from the caller, who has to allocate it.  Code under
 // HIP graph capture, a tight serving loop or a harness that forbids hipMalloc cannot: svae_masked_topk_static runs the

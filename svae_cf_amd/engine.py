@@ -779,15 +779,16 @@ class SVAEEngine:
         t, n, q, rem = cache[key]
         return (t.data_ptr(), n, q, rem)
 
-    def prepare(self, plan):
+    def prepare(self, plan, scoring=False):
         """Build and upload everything the fused step derives from a plan (the work division tables of the
         projection sweeps) BEFORE the step is launched.  Built lazily instead, the upload is a synchronous copy on
         the caller's stream in the middle of backward: the host waits for the GRU's BPTT and the weight-gradient
-        sweep starts after it rather than beside it (seen in a kernel trace: +0.2-0.4 ms on a plan's first step)."""
+        sweep starts after it rather than beside it (seen in a kernel trace: +0.2-0.4 ms on a plan's first step).
+        scoring: the plan will only be scored (``score``: the loss-only sweep over all rows)."""
         if not self.fused:
             return plan
-        want = [("rows", None, None), ("items", None, None)]
-        if self.time_split and plan.split_t > 0:
+        want = [("rows", None, None)] if scoring else [("rows", None, None), ("items", None, None)]
+        if not scoring and self.time_split and plan.split_t > 0:
             want += [("rows", plan.split_r, self._ncu - (plan.B + 3) // 4), ("rows", plan.R - plan.split_r, self._ncu)]
         made = [m for m in (self._proj_sched(plan, sd, nx=nx, ncu=ncu, host_only=True) for sd, nx, ncu in want)
                 if m is not None]

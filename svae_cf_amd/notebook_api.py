@@ -501,23 +501,43 @@ def _user_metrics(rec, held_lists, Ks=(10, 100)):
     All users at once: one [held entries x max(Ks)] comparison finds each held-out item's rank, ``np.bincount`` with
     weights sums a user's hits and discounts in held-out order (the same float64 additions, in the same order, as
     the reference's accumulation).  Returns {"NDCG@10": [U] float64, ...}."""
-    rec = np.asarray(rec)
     U = len(held_lists)
+    n_held = np.fromiter((len(h) for h in held_lists), dtype=np.int64, count=U)
+    flat = (np.concatenate([np.asarray(h, dtype=np.int64) for h in held_lists]) if U else np.zeros(0, dtype=np.int64))
+    return _user_metrics_flat(rec, flat, n_held, Ks)
+
+
+def _user_metrics_flat(rec, flat, n_held, Ks=(10, 100)):
+    """_user_metrics with the held-out items of all users as ONE array `flat` and their counts `n_held` (what
+    evaluate() keeps per reader, so that a batch's metric arithmetic has no per-user Python work)."""
+    rec = np.asarray(rec)
+    U = len(n_held)
     if max(Ks) > _KMAX or rec.shape[1] < max(Ks):
         raise ValueError("rankings must hold max(Ks) <= %d columns" % _KMAX)
-    n_held = np.fromiter((len(h) for h in held_lists), dtype=np.int64, count=U)
     if (n_held == 0).any():
         raise ZeroDivisionError("a user without held-out items (the reference divides by zero there too, nb:646)")
-    flat = np.concatenate([np.asarray(h, dtype=np.int64) for h in held_lists])
     owner = np.repeat(np.arange(U), n_held)
-    match = rec[owner].astype(np.int64) == flat[:, None]                 # [N, kmax]
-    found = match.any(axis=1)
-    rank = match.argmax(axis=1)                                           # 0-based position in the ranking
+    if rec.dtype != flat.dtype:
+        flat = flat.astype(rec.dtype) if (len(flat) == 0 or flat.max() <= np.iinfo(rec.dtype).max) else flat
+    match = rec[owner] == flat[:, None]                                   # [N, kmax]
+    rank = np.where(match.any(axis=1), match.argmax(axis=1), -1)          # 0-based position in the ranking, -1: absent
+    return _metrics_from_ranks(rank, n_held, Ks)
+
+
+def _metrics_from_ranks(rank, n_held, Ks=(10, 100)):
+    """The float64 arithmetic of nb:637-648 given, for every held-out item (users concatenated, `n_held` per user),
+    its 0-based position in the user's ranking or -1 (what svae_heldout_ranks computes on the device)."""
+    rank = np.asarray(rank, dtype=np.int64)
+    n_held = np.asarray(n_held, dtype=np.int64)
+    U = len(n_held)
+    if (n_held == 0).any():
+        raise ZeroDivisionError("a user without held-out items (the reference divides by zero there too, nb:646)")
+    owner = np.repeat(np.arange(U), n_held)
     out = {}
     for k in Ks:
-        hit = found & (rank < k)
+        hit = (rank >= 0) & (rank < k)
         hits = np.bincount(owner, weights=hit.astype(np.float64), minlength=U)
-        dcg = np.bincount(owner, weights=np.where(hit, _INV_LOG2[rank + 2], 0.0), minlength=U)
+        dcg = np.bincount(owner, weights=np.where(hit, _INV_LOG2[np.maximum(rank, 0) + 2], 0.0), minlength=U)
         best = _IDEAL[np.minimum(n_held, k)]
         out["NDCG@%d" % k] = dcg / best
         out["Rec@%d" % k] = hits / n_held.astype(np.float64)
@@ -541,45 +561,90 @@ def _metrics_from_rankings(rec, held_lists, n_inputs, Ks=(10, 100)):
     return sums, len_map
 
 
-def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=64, eps_list=None, seed=0,
-             rank=0, world=1, group=None):
+def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=256, eps_list=None, seed=0,
+             rank=0, world=1, group=None, workers=2):
     """nb:594-666.  Returns (metrics dict with the reference's 7 keys, len_to_ndcg_at_100_map).
     Users are scored in batches; the loss is the mean of per-user reference losses at anneal 0.2
     (nb:617), divided by ``batch`` exactly as the reference does (nb:658, one more than the users
     scored when the train-set early break fired, nb:612-613).
 
+    Pipelined (round 3): the plans of the user batches are built by the library's host-side builder on worker
+    threads and uploaded ahead of the GPU (``batch.PlanPrefetcher`` over ONE flat copy of the fold-in lists, as
+    ``train_batched`` does); the top-100 ids of a batch come back through a pinned buffer with an asynchronous copy
+    and its metric arithmetic (nb:626-654) runs on the host while the NEXT batch is being scored; the per-batch losses
+    stay on the device until the end, and so does the hit search of nb:636-645 (``svae_heldout_ranks``: the position of
+    every held-out item in its user's top-100); one read-back at the end feeds the float64 metric arithmetic of
+    nb:637-654 for all users.  Nothing synchronises per batch.
+
     world > 1 (data parallel, torch.distributed initialised): the user batches are dealt round-robin to the ranks,
     every rank scores its share, and the per-user metric rows (7 float64 per user) and per-batch loss sums are
     all-gathered; every rank then adds them up in the single-process order, so the result is bit-identical to a
     world-size-1 call whatever the number of ranks (noise is keyed by user, not by rank)."""
+    from .batch import PlanPrefetcher, UserCSR, pack_rows
     eng = model.engine
-    pairs = reader.eval_users()
-    batch = len(pairs)
-    if is_train_set and len(pairs) > hyper_params["train_cp_users"]:
-        pairs = pairs[:hyper_params["train_cp_users"]]
-        batch = len(pairs) + 1
+    # the reader's (fold-in, held-out) split (nb:536-546) and its flat copies are made once per reader and split kind
+    ckey = ("_svae_eval_csr", bool(is_train_set), hyper_params.get("train_cp_users"),
+            reader.hyper_params.get("number_users_to_keep") if hasattr(reader, "hyper_params") else None)
+    cache = getattr(reader, "_svae_eval_cache", None)
+    if cache is None or cache[0] != ckey or cache[1] is not reader.data:
+        pairs = reader.eval_users()
+        batch = len(pairs)
+        if is_train_set and len(pairs) > hyper_params["train_cp_users"]:
+            pairs = pairs[:hyper_params["train_cp_users"]]
+            batch = len(pairs) + 1
+        hcnt = np.fromiter((len(h) for _, h in pairs), dtype=np.int64, count=len(pairs))
+        hoff = np.zeros(len(pairs) + 1, dtype=np.int64)
+        np.cumsum(hcnt, out=hoff[1:])
+        hflat = np.fromiter((i for _, h in pairs for i in h), dtype=np.int32, count=int(hoff[-1]))
+        cache = (ckey, reader.data, UserCSR([f for f, _ in pairs]), hflat, hoff, pairs, batch)
+        try:
+            reader._svae_eval_cache = cache
+        except AttributeError:
+            pass
+    pairs, batch = cache[5], cache[6]
     k = reader._k()
     Ks = (10, 100)
     names = ["%s@%d" % (nm, kk) for kk in Ks for nm in ("NDCG", "Rec", "Prec")]
     mine = {}                        # chunk start -> (loss * users, per-user metric rows [n, 6])
     starts = list(range(0, len(pairs), batch_size))
-    for ci, s in enumerate(starts):
-        if ci % world != rank:
-            continue
-        chunk = pairs[s:s + batch_size]
-        plan = build_plan([np.asarray(f) for f, _ in chunk], k, user_keys=np.arange(s, s + len(chunk)),
-                          device=eng.device, total_items=eng.I)
+    my_starts = [s for ci, s in enumerate(starts) if ci % world == rank]
+    csr, hflat, hoff = cache[2], cache[3], cache[4]
+    batches = [np.arange(s, min(s + batch_size, len(pairs)), dtype=np.int64) for s in my_starts]
+    plans = PlanPrefetcher(batches, csr, k, eng.device, total_items=eng.I,
+                           prepare=lambda p_: eng.prepare(p_, scoring=True), workers=workers, depth=2 * max(1, workers))
+    kmax = max(Ks)
+    t_begin = time.perf_counter()
+    loss_dev = torch.zeros(max(1, len(my_starts)), device=eng.device, dtype=torch.float32)
+    # the hit search of nb:636-645 runs on the device (svae_heldout_ranks): every held-out item's position in its
+    # user's top-100, written into ONE array for the whole evaluation and read back once at the end
+    hflat_d = torch.from_numpy(hflat).to(eng.device)
+    hoff_d = torch.from_numpy(hoff).to(eng.device)
+    rank_dev = torch.full((max(1, len(hflat)),), -2, device=eng.device, dtype=torch.int32)
+    for ci, (s0, plan) in enumerate(zip(my_starts, plans)):
+        n = plan.B
         eps = None
         if eps_list is not None:
-            from .batch import pack_rows
-            eps = torch.from_numpy(pack_rows(plan, eps_list[s:s + len(chunk)], L)).to(eng.device)
-        out, idx, _, _ = eng.score(plan, max(Ks), eps=eps, seed=seed, step=s)
-        idx = idx.cpu().numpy()
-        inv = np.empty(len(chunk), dtype=np.int64)
-        inv[plan.order] = np.arange(len(chunk))
-        per = _user_metrics(idx[inv], [h for _, h in chunk], Ks)
-        mine[s] = (float(out[0]) * len(chunk),                 # engine loss = mean over the chunk's users
-                   np.stack([per[n] for n in names], axis=1))
+            eps = torch.from_numpy(pack_rows(plan, eps_list[s0:s0 + n], L)).to(eng.device)
+        out, idx, _, _ = eng.score(plan, kmax, eps=eps, seed=seed, step=s0)
+        loss_dev[ci].copy_(out[0])
+        _lib.call("svae_heldout_ranks", idx.data_ptr(), n, int(idx.shape[1]), plan.row_key.data_ptr(), plan.last_row.data_ptr(),
+                  hflat_d.data_ptr(), hoff_d.data_ptr(), len(pairs), rank_dev.data_ptr(), _stream())
+    t_loop = time.perf_counter()
+    rank_all = rank_dev.cpu().numpy()
+    t_sync = time.perf_counter()
+    for s0 in my_starts:
+        n = min(batch_size, len(pairs) - s0)
+        r = rank_all[hoff[s0]:hoff[s0 + n]]
+        if len(r) and r.min() < -1:
+            raise RuntimeError("evaluate: a scored user's held-out ranks were not written (user keys of the plan?)")
+        per = _metrics_from_ranks(r, np.diff(hoff[s0:s0 + n + 1]), Ks)
+        mine[s0] = np.stack([per[nm] for nm in names], axis=1)
+    losses = loss_dev.cpu().numpy() if my_starts else np.zeros(0, dtype=np.float32)
+    # (diagnostic: host time of the scoring loop, of it blocked on plans, then the wait for the GPU, then the metrics)
+    evaluate.last_timing = dict(loop_s=t_loop - t_begin, plans_wait_s=plans.wait_s, drain_s=t_sync - t_loop,
+                                metrics_s=time.perf_counter() - t_sync)
+    # engine loss = mean over the batch's users
+    mine = {s0: (float(losses[ci]) * len(pairs[s0:s0 + batch_size]), mine[s0]) for ci, s0 in enumerate(my_starts)}
     if world > 1:
         import torch.distributed as dist
         parts = [None] * world

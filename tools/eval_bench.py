@@ -68,7 +68,55 @@ e1.synchronize()
 us_big = e0.elapsed_time(e1) * 1e3 / 10
 ok = bool((torch.topk(big[:, :I], 100, dim=1).indices.to(torch.int32).reshape(-1) == bidx).all())
 algo = B * I * 4 + B * 100 * 8
+
+# END TO END through the public entry point: notebook_api.evaluate over a validation-type reader (fold-in + held-out
+# lists per user, as DataReader holds them): plans built from the lists by the prefetcher, scored, ids back, the metric
+# arithmetic of nb:626-654 -- against `value` above (engine.score on resident plans, nothing else).
+from svae_cf_amd import notebook_api as N
+
+
+class Reader:
+    def __init__(self, us):
+        self.data = [u[:int(0.8 * len(u))].tolist() for u in us]
+        self.data_te = [u[int(0.8 * len(u)):].tolist() for u in us]
+    def eval_users(self): return list(zip(self.data, self.data_te))
+    def _k(self): return 4
+
+
+class M:                       # the part of notebook_api.Model evaluate() reads
+    engine = eng
+
+
+NU = int(os.environ.get("SVAE_EVAL_USERS", 32 * B))
+ev_users = synth.make_users(NU, I, mu, sigma, lmax, seed=4242)
+reader = Reader(ev_users)
+hp = dict(train_cp_users=200)
+e2e = {}
+for tag in ("warmup", "run", "run2"):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    metrics, _ = N.evaluate(M, None, reader, hp, False, batch_size=B, seed=1)
+    torch.cuda.synchronize()
+    e2e[tag] = time.perf_counter() - t0
+    e2e[tag + "_timing"] = dict(N.evaluate.last_timing)
+# the same users with plans resident and nothing but engine.score (the bar: 0.7 x this rate)
+res_plans = [S.build_plan([np.asarray(reader.data[i]) for i in range(s, min(s + B, NU))], 4,
+                          user_keys=np.arange(s, min(s + B, NU)), device="cuda", total_items=I) for s in range(0, NU, B)]
+for p_ in res_plans:
+    eng.prepare(p_, scoring=True)
+    eng.score(p_, 100, seed=1, step=0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for p_ in res_plans:
+    eng.score(p_, 100, seed=1, step=0)
+torch.cuda.synchronize()
+t_res = time.perf_counter() - t0
+best = min(e2e["run"], e2e["run2"])
+end_to_end = {"entry_point": "notebook_api.evaluate(batch_size=%d)" % B, "users": NU, "seconds": [e2e["run"], e2e["run2"]],
+              "users_per_s": NU / best, "resident_score_users_per_s": NU / t_res, "ratio": t_res / best, "host_timing": [e2e["run_timing"], e2e["run2_timing"]],
+              "metrics": metrics}
 print(json.dumps({"metric": "users scored/s (ML-20M shape, top-100)", "value": n / dt, "batch": B, "items": I,
+                  "evaluate_end_to_end": end_to_end,
                   "ms_per_batch": dt / (3 * len(plans)) * 1e3,
                   "masked_topk": {"us": us, "algorithmic_bytes": algo, "GB/s": algo / us / 1e3,
                                   "frac_of_8TB/s": algo / us / 1e3 / 8000.0},
