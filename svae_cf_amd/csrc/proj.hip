@@ -55,6 +55,7 @@
 #ifdef SV_PROJ_TIMING   // diagnostic build only (tools/proj_timing.py): phase stamps of waves 0 and 4 of block 0
 __device__ unsigned long long g_proj_dbg[3][2][8];
 __device__ unsigned long long g_proj_blk[3][4096][4];   // per block (wave 0): realtime at start, at end, loop cycles, tiles
+__device__ unsigned long long g_proj_blk2[3][4096][2];  // per block (wave 0): realtime at kernel entry, behind the epilogue's stores
 __device__ unsigned long long g_proj_wv[3][8][8][8];    // block 0, per wave, tiles 8..15: cycle stamps (see SV_WSTAMP)
 #define SV_WSTAMP(k_) if (blockIdx.x == 0 && j >= 8 && j < 16 && lane == 0) g_proj_wv[MODE][wave][j - 8][k_] = __builtin_amdgcn_s_memtime();
 #define SV_TS(i_) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts_acc[i_] += now_ - ts_last; ts_last = now_; __builtin_amdgcn_sched_barrier(0); }
@@ -148,6 +149,9 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+#ifdef SV_PROJ_TIMING
+    const unsigned long long blk_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int4 sc = a.sched[blockIdx.x];
     const int xt = __builtin_amdgcn_readfirstlane(sc.x), split = __builtin_amdgcn_readfirstlane(sc.w);
     const int x0 = xt * BX + wave * 32;
@@ -830,6 +834,13 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
             }
         if (MODE == MODE_FDH && lh == 0 && xok) a.mpart[(size_t)split * a.nx + x] = any_tile ? m_eff : NEG_BIG;
     }
+#ifdef SV_PROJ_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && wave == 0 && blockIdx.x < 4096) {
+        g_proj_blk2[MODE][blockIdx.x][0] = blk_entry;
+        g_proj_blk2[MODE][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1213,6 +1224,9 @@ extern "C" int svae_debug_proj(unsigned long long* out48) {
 }
 extern "C" int svae_debug_proj_waves(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_proj_wv), sizeof(unsigned long long) * 3 * 8 * 8 * 8);
+}
+extern "C" int svae_debug_proj_blocks2(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_proj_blk2), 3 * 4096 * 2 * sizeof(unsigned long long));
 }
 extern "C" int svae_debug_proj_blocks(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_proj_blk), 3 * 4096 * 4 * sizeof(unsigned long long));

@@ -35,10 +35,22 @@ blk = (ctypes.c_ulonglong * (3 * 4096 * 4))()
 lib.svae_debug_proj_blocks.argtypes = [ctypes.c_void_p]
 lib.svae_debug_proj_blocks(ctypes.byref(blk))
 b = np.array(list(blk), dtype=np.float64).reshape(3, 4096, 4)
+blk2 = (ctypes.c_ulonglong * (3 * 4096 * 2))()
+lib.svae_debug_proj_blocks2.argtypes = [ctypes.c_void_p]
+lib.svae_debug_proj_blocks2(ctypes.byref(blk2))
+b2 = np.array(list(blk2), dtype=np.float64).reshape(3, 4096, 2)
 for mode, name in ((1, "FDH"), (2, "DW")):
     m = b[mode]
     n = int((m[:, 3] > 0).sum())
     m = m[:n]
+    e = b2[mode][:n]
+    pro, epi = (m[:, 0] - e[:, 0]) / 100.0, (e[:, 1] - m[:, 1]) / 100.0
+    print("%s: prologue us (entry -> loop start) median %.1f max %.1f; epilogue us (loop end -> stores landed) median %.1f max %.1f; "
+          "loop us median %.1f; tiles per block median %.0f" % (name, np.median(pro), pro.max(), np.median(epi), epi.max(),
+                                                                 np.median(m[:, 1] - m[:, 0]) / 100.0, np.median(m[:, 3])))
+    first = e[:, 0].min()
+    print("   whole kernel (first entry -> last store landed): %.1f us; sum of loops / (CUs x span) = %.2f"
+          % ((e[:, 1].max() - first) / 100.0, (m[:, 1] - m[:, 0]).sum() / ((256 if mode == 1 else 256) * (e[:, 1].max() - first))))
     t0 = m[:, 0].min()
     start, end = (m[:, 0] - t0) / 100.0, (m[:, 1] - t0) / 100.0     # us (100 MHz counter)
     cyc_tile = m[:, 2] / np.maximum(m[:, 3], 1)
