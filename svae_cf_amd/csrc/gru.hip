@@ -320,6 +320,37 @@ __device__ __forceinline__ bf16x8 load_w8(const float* p) {
     return v;
 }
 
+// Split instantiation ("prec 2"): an fp32 value as bf16 hi + mid + lo parts (all 24 significant bits), and a product by
+// its six leading terms on the bf16 MFMA pipe, small terms first -- as in the split instantiations of the other
+// fused kernels (proj.hip, mlp.hip, rowgemm.hip, wgrad.hip).
+__device__ __forceinline__ void split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = sv_f2bf(v);
+    const float r1 = v - sv_bf2f(h);
+    m = sv_f2bf(r1);
+    l = sv_f2bf(r1 - sv_bf2f(m));
+}
+__device__ __forceinline__ void load_w8_split(const float* p, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const float4 lo = *reinterpret_cast<const float4*>(p);
+    const float4 hi = *reinterpret_cast<const float4*>(p + 4);
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned short a, b, c;
+        split3(v[i], a, b, c);
+        h[i] = (short)a; m[i] = (short)b; l[i] = (short)c;
+    }
+}
+__device__ __forceinline__ f32x4 mfma_split(const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh,
+                                            const bf16x8 bm, const bf16x8 bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+
 // Re-deal of a 16x16 accumulator tile whose rows 0..3 are the real users (registers 0..3 of lanes 0..15): lane
 // 16 u + n receives row u, column n.  Two row swaps and one half swap in registers (gfx950's v_permlane16_swap /
 // v_permlane32_swap; semantics checked by tools/probe/permlane_probe.hip) instead of a round trip through an LDS
@@ -350,21 +381,34 @@ constexpr int XS_FLOATS = 2 * 3 * 64;              // re-deal scratch of one wav
 #ifndef SV_GRU_ALT
 #define SV_GRU_ALT 1
 #endif
-template <int NQ>  // number of hidden tiles this wave owns (2 for waves 0..5; 1 for waves 6,7)
+// SPLIT: the parity instantiation of the SAME recurrence kernel (prec 2, used by PREC_SPLIT): same work division
+// (MU users per workgroup, 8 waves, wave w owns hidden tiles w and w + 8, lane 16 u + n owns user u of unit n), same
+// branch-free step (out-of-range buffer offsets for inactive users, input gates fetched one step ahead, accumulator rows
+// re-dealt by lane swaps, one barrier per timestep, ping-pong h image), but fp32-class arithmetic: h is published as
+// bf16 hi + mid + lo images, every W_hh fragment is split the same way and every product taken by its six leading
+// terms; sigmoid / tanh are the exact ones of the fp32 kernel.  The weight fragments are NOT resident (three parts of
+// 301 KB): they are re-read from L2 and split every step, and the per-tile alternation is off -- this instantiation is
+// never timed.  The mid / lo images live where the bf16 instantiation keeps its LDS-resident weight tiles.
+template <int NQ, bool SPLIT>  // NQ: number of hidden tiles this wave owns (2 for waves 0..5; 1 for waves 6,7)
 __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned short* h_bf, unsigned short* w_lds,
                                                   float* xs, int wave, int lane) {
     const int u0 = blockIdx.x * MU;
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_HP / 32;  // 7 k-steps
-    constexpr int NL = NQ - 1;      // tiles in LDS
-    constexpr bool ALT = SV_GRU_ALT != 0;
+    constexpr int NL = SPLIT ? 0 : NQ - 1;      // tiles in LDS
+    constexpr bool ALT = SV_GRU_ALT != 0 && !SPLIT;
+    constexpr int HIMG = 2 * MB * HLDB;          // elements of one ping-pong h image pair
+    unsigned short* const h_mid = w_lds;         // (SPLIT only)
+    unsigned short* const h_lo = w_lds + HIMG;
 
-    bf16x8 W[3][KS];
+    bf16x8 W[SPLIT ? 1 : 3][SPLIT ? 1 : KS];
+    if constexpr (!SPLIT) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             W[g][s] = load_w8(a.whh + (size_t)(g * SV_HP + 16 * wave + ln) * SV_HP + 32 * s + 8 * lk);
+    }
     unsigned short* wl = w_lds + (size_t)wave * (WL_FRAGS * 64 * 8) + lane * 8;
     if (NL > 0) {
 #pragma unroll
@@ -412,6 +456,12 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
                 const int j = 16 * (wave + 8 * q) + ln;
                 const float h = a.hs[row * SV_HP + j];
                 hreg[q] = h;
+                if constexpr (SPLIT) {
+                    unsigned short p0, p1, p2;
+                    split3(h, p0, p1, p2);
+                    const int o = (a.t0 & 1) * (MB * HLDB) + lk * HLDB + j;
+                    h_bf[o] = p0; h_mid[o] = p1; h_lo[o] = p2;
+                } else
                 hinit[lk * HLDB + j] = sv_f2bf(h);
             }
         }
@@ -466,6 +516,32 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
                     gi_nx[q][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gi_b, ogn + (g * SV_HP + 128 * q) * 4, 0, 0));
         }
 
+        f32x4 acc[NQ][3];
+        float gh[NQ][3];
+        float a_er = 0.f, a_ez = 0.f, a_rg = 0.f, a_zg = 0.f, a_en = 0.f, a_ng = 0.f, a_hn = 0.f;
+        if constexpr (SPLIT) {
+            const int ho = (t & 1) * (MB * HLDB) + ln * HLDB + 8 * lk;
+            bf16x8 Ah[KS], Am[KS], Al[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                Ah[s] = *reinterpret_cast<const bf16x8*>(h_bf + ho + 32 * s);
+                Am[s] = *reinterpret_cast<const bf16x8*>(h_mid + ho + 32 * s);
+                Al[s] = *reinterpret_cast<const bf16x8*>(h_lo + ho + 32 * s);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    f32x4 c = (f32x4){bias[q][g], bias[q][g], bias[q][g], bias[q][g]};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        bf16x8 wh, wm, wl_;
+                        load_w8_split(a.whh + (size_t)(g * SV_HP + 16 * (wave + 8 * q) + ln) * SV_HP + 32 * s + 8 * lk, wh, wm, wl_);
+                        c = mfma_split(Ah[s], Am[s], Al[s], wh, wm, wl_, c);
+                    }
+                    acc[q][g] = c;
+                }
+        } else {
         bf16x8 A[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) A[s] = *reinterpret_cast<const bf16x8*>(hcur + ln * HLDB + 32 * s + 8 * lk);
@@ -473,7 +549,6 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         SV_TS(1)
-        f32x4 acc[NQ][3];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -500,8 +575,6 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
         // k-step groups of tile 1's MFMAs -- a wave issues in order, so vector work placed behind its last MFMA only
         // starts when the pipe has taken all of them; in the gaps it costs nothing and the partner wave's MFMAs fill
         // the pipe meanwhile.  sched_barrier(0) pins each slice to its gap.  Same arithmetic, same order per element.
-        float gh[NQ][3];
-        float a_er = 0.f, a_ez = 0.f, a_rg = 0.f, a_zg = 0.f, a_en = 0.f, a_ng = 0.f, a_hn = 0.f;
 #define SV_SLICE_FENCE __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NGRP; ++i) {
@@ -538,6 +611,7 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
         SV_TS(2)
 #undef SV_WLOAD
 #undef SV_PIN_ORDER
+        }
         // re-deal: every lane picks its (user lk, unit ln) values out of rows 0..3 of the accumulator tiles
         constexpr bool DONE0 = NQ == 2 && ALT;      // tile 0 went through its gate math between tile 1's MFMAs
 #pragma unroll
@@ -556,15 +630,31 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
 #pragma unroll
         for (int q = DONE0 ? 1 : 0; q < NQ; ++q) {
             const int j = 16 * (wave + 8 * q) + ln;
-            const float er = __builtin_amdgcn_exp2f((gi[q][0] + gh[q][0]) * -1.4426950408889634f) + 1.0f;
-            const float ez = __builtin_amdgcn_exp2f((gi[q][1] + gh[q][1]) * -1.4426950408889634f) + 1.0f;
-            const float rg = __builtin_amdgcn_rcpf(er), zg = __builtin_amdgcn_rcpf(ez);
-            const float en = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, gh[q][2], gi[q][2]) * -2.8853900817779268f) + 1.0f;
-            const float ng = __builtin_amdgcn_rcpf(en) * 2.0f - 1.0f;
+            float rg, zg, ng, hn;
             const float hp = hreg[q];
-            const float hn = __builtin_fmaf(zg, hp - ng, ng);
+            if constexpr (SPLIT) {      // the fp32 kernel's gate math (gate_fwd<false>)
+                rg = sv_sigmoid(gi[q][0] + gh[q][0]);
+                zg = sv_sigmoid(gi[q][1] + gh[q][1]);
+                ng = tanhf(gi[q][2] + rg * gh[q][2]);
+                hn = (1.0f - zg) * ng + zg * hp;
+            } else {
+                const float er = __builtin_amdgcn_exp2f((gi[q][0] + gh[q][0]) * -1.4426950408889634f) + 1.0f;
+                const float ez = __builtin_amdgcn_exp2f((gi[q][1] + gh[q][1]) * -1.4426950408889634f) + 1.0f;
+                rg = __builtin_amdgcn_rcpf(er), zg = __builtin_amdgcn_rcpf(ez);
+                const float en = __builtin_amdgcn_exp2f(__builtin_fmaf(rg, gh[q][2], gi[q][2]) * -2.8853900817779268f) + 1.0f;
+                ng = __builtin_amdgcn_rcpf(en) * 2.0f - 1.0f;
+                hn = __builtin_fmaf(zg, hp - ng, ng);
+            }
             hreg[q] = hn;
             s_hn[q] = hn; s_hp[q] = hp; s_rg[q] = rg; s_zg[q] = zg; s_ng[q] = ng;
+            if constexpr (SPLIT) {
+                if (lk < MU) {
+                    unsigned short p0, p1, p2;
+                    split3(hn, p0, p1, p2);
+                    const int o = ((t + 1) & 1) * (MB * HLDB) + lk * HLDB + j;
+                    h_bf[o] = p0; h_mid[o] = p1; h_lo[o] = p2;
+                }
+            } else
             if (lk < MU) hnxt[lk * HLDB + j] = sv_f2bf(hn);
         }
         SV_TS(4)
@@ -593,36 +683,46 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
 #endif
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(64 * FWD_WAVES, 1) void gru_fwd_bf16_kernel(GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_f[];
-    unsigned short* w_lds = smem_f;                // 6 tiles x [21][64][8]
+    unsigned short* w_lds = smem_f;                // 6 tiles x [21][64][8]   (SPLIT: the mid and lo h images)
     unsigned short* h_bf = smem_f + WLF_ELEMS;     // [2][MB][HLDB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* xs = reinterpret_cast<float*>(h_bf + 2 * MB * HLDB) + wave * XS_FLOATS;   // per-wave re-deal scratch
     for (int i = tid; i < 2 * MB * HLDB; i += 64 * FWD_WAVES) h_bf[i] = 0;
+    if (SPLIT)
+        for (int i = tid; i < 4 * MB * HLDB; i += 64 * FWD_WAVES) w_lds[i] = 0;
     __syncthreads();
     if (wave < 6)
-        gru_fwd_bf16_body<2>(a, h_bf, w_lds, xs, wave, lane);
+        gru_fwd_bf16_body<2, SPLIT>(a, h_bf, w_lds, xs, wave, lane);
     else
-        gru_fwd_bf16_body<1>(a, h_bf, w_lds, xs, wave, lane);
+        gru_fwd_bf16_body<1, SPLIT>(a, h_bf, w_lds, xs, wave, lane);
 }
 
 // Backward: same organisation as the forward (8 waves, wave w owns hidden tiles w and w+8, the second one
 // LDS-resident; MU users per workgroup, masked lanes get out-of-range buffer offsets).  The dgh image only has
 // MU real rows: the MFMA rows of padding users alias them (row = ln % MU), their results are discarded.
-template <int NQ>
+// SPLIT: as in the forward kernel -- the dgh image as bf16 hi + mid + lo parts, the W_hh^T fragments re-read and split
+// every step, six products per fragment pair; the gate-gradient arithmetic is exact fp32 in both instantiations.
+template <int NQ, bool SPLIT>
 __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned short* g_bf, unsigned short* w_lds,
                                                   float* xs, int wave, int lane) {
     const int u0 = blockIdx.x * MU;
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_G / 32;  // 21 k-steps
-    constexpr int NL = NQ - 1;
+    constexpr int NL = SPLIT ? 0 : NQ - 1;
+    constexpr int GIMG = 2 * MU * GLDB;          // elements of one ping-pong dgh image pair
+    unsigned short* const g_mid = w_lds;         // (SPLIT only)
+    unsigned short* const g_lo = w_lds + GIMG;
 
     // B operand of dh_{t-1} = dgh W_hh: B[k = gate column c][n = hidden j'] = W_hh[c][j'] = whh_t[j'][c]
-    bf16x8 W[KS];
+    bf16x8 W[SPLIT ? 1 : KS];
+    if constexpr (!SPLIT) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) W[s] = load_w8(a.whh + (size_t)(16 * wave + ln) * SV_G + 32 * s + 8 * lk);
+    }
     unsigned short* wl = w_lds + (size_t)wave * (WL_FRAGS * 64 * 8) + lane * 8;
     if (NL > 0) {
 #pragma unroll
@@ -716,6 +816,18 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnr), gh_b, ogo + 512 * q + 2 * SV_HP * 4, 0, 0);
                 }
             }
+            if constexpr (SPLIT) {
+                if (lk < MU) {
+                    const int o = (t & 1) * (MU * GLDB) + lk * GLDB + j;
+                    unsigned short p0, p1, p2;
+                    split3(drp, p0, p1, p2);
+                    g_bf[o] = p0; g_mid[o] = p1; g_lo[o] = p2;
+                    split3(dzp, p0, p1, p2);
+                    g_bf[o + SV_HP] = p0; g_mid[o + SV_HP] = p1; g_lo[o + SV_HP] = p2;
+                    split3(dnr, p0, p1, p2);
+                    g_bf[o + 2 * SV_HP] = p0; g_mid[o + 2 * SV_HP] = p1; g_lo[o + 2 * SV_HP] = p2;
+                }
+            } else
             if (lk < MU) {   // MU = 4: every lane owns an image row
                 gcur[lk * GLDB + j] = sv_f2bf(drp);
                 gcur[lk * GLDB + SV_HP + j] = sv_f2bf(dzp);
@@ -728,6 +840,21 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
             f32x4 acc[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) {
+                const int go = (t & 1) * (MU * GLDB) + (ln % MU) * GLDB + 8 * lk;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(g_bf + go + 32 * s);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(g_mid + go + 32 * s);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(g_lo + go + 32 * s);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        bf16x8 wh, wm, wl_;
+                        load_w8_split(a.whh + (size_t)(16 * (wave + 8 * q) + ln) * SV_G + 32 * s + 8 * lk, wh, wm, wl_);
+                        acc[q] = mfma_split(ah, am, al, wh, wm, wl_, acc[q]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int s0 = 0; s0 < KS; s0 += 7) {
                 bf16x8 A[7];
@@ -755,17 +882,18 @@ __device__ __forceinline__ void gru_bwd_bf16_body(const GruArgs& a, unsigned sho
 #undef SV_GRU_BWD_FETCH
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(64 * FWD_WAVES, 1) void gru_bwd_bf16_kernel(GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_b[];
-    unsigned short* w_lds = smem_b;                // 6 tiles x [21][64][8]
+    unsigned short* w_lds = smem_b;                // 6 tiles x [21][64][8]   (SPLIT: the mid and lo dgh images)
     unsigned short* g_bf = smem_b + WLF_ELEMS;     // [2][MU][GLDB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* xs = reinterpret_cast<float*>(g_bf + 2 * MU * GLDB) + wave * 128;     // per-wave re-deal scratch
     if (wave < 6)
-        gru_bwd_bf16_body<2>(a, g_bf, w_lds, xs, wave, lane);
+        gru_bwd_bf16_body<2, SPLIT>(a, g_bf, w_lds, xs, wave, lane);
     else
-        gru_bwd_bf16_body<1>(a, g_bf, w_lds, xs, wave, lane);
+        gru_bwd_bf16_body<1, SPLIT>(a, g_bf, w_lds, xs, wave, lane);
 }
 
 }  // namespace
@@ -796,9 +924,9 @@ extern "C" int svae_gru_fwd_range(const float* gi, const float* whh, const float
                                   float* gates4, int prec, void* stream) {
     GruArgs a{gi, whh, bhh, row_off, nact, hs, hprev, gates4, nullptr, nullptr, nullptr, B, Tmax, 0, t0, t1};
     if (int e = check_gru(a, false)) return e;
-    SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gru_fwd: bad prec %d", prec);
+    SV_CHECK_ARG(prec == 0 || prec == 1 || prec == 2, "svae_gru_fwd: bad prec %d", prec);
     SV_CHECK_ARG(t0 >= 0 && t0 < t1 && t1 <= Tmax, "svae_gru_fwd_range: bad range [%d, %d) of %d", t0, t1, Tmax);
-    SV_CHECK_ARG(prec == 1 || (t0 == 0 && t1 == Tmax), "svae_gru_fwd_range: the fp32 kernel runs whole sequences only");
+    SV_CHECK_ARG(prec != 0 || (t0 == 0 && t1 == Tmax), "svae_gru_fwd_range: the fp32 kernel runs whole sequences only");
     dim3 grid((B + MB - 1) / MB);
     if (prec == 0) {
         hipLaunchKernelGGL(gru_fwd_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -807,9 +935,14 @@ extern "C" int svae_gru_fwd_range(const float* gi, const float* whh, const float
         SV_CHECK_ARG((long long)B * Tmax < (1ll << 19), "svae_gru_fwd: B*Tmax = %lld rows exceed the 32-bit addressing "
                      "of the bf16 kernel (2^19 rows); split the batch", (long long)B * Tmax);
         const int lds = (WLF_ELEMS + 2 * MB * HLDB) * sizeof(unsigned short) + FWD_WAVES * XS_FLOATS * 4;   // 156 KiB of the CU's 160
-        hipError_t e = hipFuncSetAttribute((const void*)gru_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        // prec 2: the split instantiation of the same kernel (fp32-class; see gru_fwd_bf16_body)
+        const void* fn = prec == 2 ? (const void*)gru_fwd_bf16_kernel<true> : (const void*)gru_fwd_bf16_kernel<false>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_fwd: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(gru_fwd_bf16_kernel, dim3((B + MU - 1) / MU), dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);
+        if (prec == 2)
+            hipLaunchKernelGGL(gru_fwd_bf16_kernel<true>, dim3((B + MU - 1) / MU), dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(gru_fwd_bf16_kernel<false>, dim3((B + MU - 1) / MU), dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);
     }
     SV_LAUNCH_CHECK();
     return 0;
@@ -860,9 +993,10 @@ static int gru_bwd_launch(const float* dhs, const float* hprev, const float* gat
     GruArgs a{nullptr, whh_t, nullptr, row_off, nact, nullptr, const_cast<float*>(hprev),
               const_cast<float*>(gates4), dhs, dgi, merged ? dgi : dgh, B, Tmax, merged, t0, t1, dh_carry};
     if (int e = check_gru(a, true)) return e;
-    SV_CHECK_ARG(prec == 1 || (t0 == 0 && t1 == Tmax), "svae_gru_bwd: time ranges need the bf16 kernel");
-    SV_CHECK_ARG(prec == 0 || prec == 1, "svae_gru_bwd: bad prec %d", prec);
-    SV_CHECK_ARG(!merged || prec == 1, "svae_gru_bwd: the merged gradient array needs the bf16 kernel");
+    SV_CHECK_ARG(prec != 0 || (t0 == 0 && t1 == Tmax), "svae_gru_bwd: time ranges need the bf16 kernel");
+    SV_CHECK_ARG(prec == 0 || prec == 1 || prec == 2, "svae_gru_bwd: bad prec %d", prec);
+    SV_CHECK_ARG(!merged || prec != 0, "svae_gru_bwd: the merged gradient array needs the bf16 kernel template");
+    SV_CHECK_ARG(prec != 2 || merged != 2, "svae_gru_bwd: the split instantiation writes fp32 gradients");
     dim3 grid((B + MB - 1) / MB);
     if (prec == 0) {
         hipLaunchKernelGGL(gru_bwd_f32_kernel, grid, dim3(256), MB * GLD * sizeof(float), (hipStream_t)stream, a);
@@ -871,9 +1005,13 @@ static int gru_bwd_launch(const float* dhs, const float* hprev, const float* gat
         SV_CHECK_ARG((long long)B * Tmax < (1ll << 19), "svae_gru_bwd: B*Tmax = %lld rows exceed the 32-bit addressing "
                      "of the bf16 kernel (2^19 rows); split the batch", (long long)B * Tmax);
         const int lds = (WLF_ELEMS + 2 * MU * GLDB) * sizeof(unsigned short) + FWD_WAVES * 128 * 4;
-        hipError_t e = hipFuncSetAttribute((const void*)gru_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const void* fn = prec == 2 ? (const void*)gru_bwd_bf16_kernel<true> : (const void*)gru_bwd_bf16_kernel<false>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return svae_fail((int)e, "svae_gru_bwd: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(gru_bwd_bf16_kernel, grid, dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);
+        if (prec == 2)
+            hipLaunchKernelGGL(gru_bwd_bf16_kernel<true>, grid, dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(gru_bwd_bf16_kernel<false>, grid, dim3(64 * FWD_WAVES), lds, (hipStream_t)stream, a);
     }
     SV_LAUNCH_CHECK();
     return 0;

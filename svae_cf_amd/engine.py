@@ -21,9 +21,10 @@ PREC_FP32 = 0
 PREC_BF16 = 1
 # The fused bf16 kernels in their SPLIT instantiation: operands as bf16 hi + mid + lo parts (all 24 significant bits),
 # products by their six leading terms (fp32-class results from the same kernel templates, work division, slab /
-# finish structure as PREC_BF16: the projection sweeps, the MLP chain, the row-panel and weight-gradient GEMMs).  The
-# parity gates run through it; it does six times the MFMA work of PREC_BF16 and is never timed.  The GRU recurrence
-# runs its exact fp32 kernels.
+# finish structure as PREC_BF16: the projection sweeps, the MLP chain, the row-panel and weight-gradient GEMMs, and --
+# since round 3 -- the persistent GRU recurrence, forward and BPTT, with exact sigmoid / tanh).  The parity gates run
+# through it, on the same host path as the timed step (two time ranges, merged gate-gradient array, side streams); it
+# does six times the MFMA work of PREC_BF16 and is only timed for the bench line's `fp32_class` figure.
 PREC_SPLIT = 2
 
 
@@ -82,7 +83,9 @@ class SVAEEngine:
         self.I, self.IP = self.layout.I, self.layout.IP
         self.prec = prec
         self.split = prec == PREC_SPLIT
-        self.gru_prec = PREC_FP32 if self.split else prec
+        # PREC_SPLIT runs the recurrence through the split instantiation of the TIMED kernel template (gru.hip, prec 2)
+        # since round 3; SVAE_SPLIT_GRU_F32=1 restores the generic fp32 kernels of rounds 1-2 in that mode
+        self.gru_prec = PREC_FP32 if (self.split and os.environ.get("SVAE_SPLIT_GRU_F32", "0") == "1") else prec
         self.gemm_prec = PREC_FP32 if self.split else prec         # generic GEMM (dense surface): fp32 or bf16
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
         n = self.layout.total
@@ -487,7 +490,7 @@ class SVAEEngine:
         # With a two-range forward (below) only the rows of the first range's timesteps are needed by the recurrence
         # that heads the step: their gather and input gates here, the others' on the side stream beside it (+1.2 %).
         gi_split = (plan.split_r if (self.fused and self.rowgemm and self.gi_split and self.overlap and self.time_split
-                                     and want_loss and want_grad and self.gru_prec == PREC_BF16 and plan.split_t > 0)
+                                     and want_loss and want_grad and self.gru_prec in (PREC_BF16, PREC_SPLIT) and plan.split_t > 0)
                     else 0)
         head_fused = self.fused and self.rowgemm and self.prec == PREC_BF16 and self.head_fused
         # (bf16 rows need the bf16 gradient array on the other side: the weight-gradient kernel's bf16-X form reads both)
@@ -529,7 +532,7 @@ class SVAEEngine:
         # the decoder side of the rows of steps < t1 (rows are time-major: the first r1 of them).
         side_prep = self.fused and self.overlap
         t1, r1 = (plan.split_t, plan.split_r) if (self.time_split and side_prep and want_loss
-                                                  and want_grad and self.gru_prec == PREC_BF16) else (0, 0)
+                                                  and want_grad and self.gru_prec in (PREC_BF16, PREC_SPLIT)) else (0, 0)
 
         def gru_range(a, b, tag):
             ev = self._tic(tag)
@@ -701,8 +704,8 @@ class SVAEEngine:
             self._toc("mlp_fwd", ev)
         else:
             self._mlp_fwd_rows(r0, r1)
-            _lib.call("svae_proj_prep_rows_range", w["d1"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
-                      w["h2b"].data_ptr(), w["h2s"].data_ptr(), _lib.ptr(w["h2tb"]), _stream())
+            _lib.call("svae_proj_prep_rows_range_split", w["d1"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
+                      w["h2b"].data_ptr(), w["h2s"].data_ptr(), _lib.ptr(w["h2tb"]), self._ps("rows"), _stream())
         if not sweep:
             return
         nsm = _lib.load().svae_proj_ns_max()
@@ -713,7 +716,8 @@ class SVAEEngine:
                 w["pslabs"].data_ptr() + 4 * nsm * DP * r0, w["mpart"].data_ptr() + 4 * nsm * r0,
                 w["nll_row"].data_ptr() + 4 * r0, w["lse"].data_ptr() + 4 * r0,
                 w["dd1"].data_ptr() + 4 * DP * r0) + self._proj_sched(plan, "rows", nx=n, ncu=ncu)
-        self._split_call("svae_proj_nll_fwd_dh", args, ((1, "proj_fdh_fused"), (2, "proj_fdh_finish")))
+        self._split_call("svae_proj_nll_fwd_dh", args, ((1, "proj_fdh_fused"), (2, "proj_fdh_finish")),
+                         strides=(self._ps("rows"), self._ps("items")))
 
     def _split_call(self, name, args, parts, strides=None):
         """One C-ABI call covering several kernels; when profiling, one call per kernel so each is bracketed.
@@ -951,12 +955,12 @@ class SVAEEngine:
         ev = self._tic("gru_bwd")
         # bf16 kernels: ONE gradient array [R][896] = (dr, dz, dn, dn*r) instead of dgi and dgh (they differ in the third
         # gate only): a third fewer stores in every BPTT step
-        merged = self.fused and self.rowgemm and self.gru_prec == PREC_BF16 and self.merged_dg
+        merged = self.fused and self.rowgemm and self.gru_prec in (PREC_BF16, PREC_SPLIT) and self.merged_dg
         # ... and as bf16 elements: its three MFMA consumers round it to bf16 anyway (RNE there as here), so the weight
         # and embedding gradients are bit-identical and the array is written once and read three times at half the
         # bytes; only the two GRU bias gradients (column sums of the array) see the rounding, 2e-4 relative
         # (tests/test_gpu_fullsize.py::test_gru_gradient_array_forms_agree)
-        dg16 = merged and self.dg_bf16 and prepped
+        dg16 = merged and self.dg_bf16 and prepped and self.gru_prec == PREC_BF16     # (split: fp32 elements)
         dgi, ldg = (w["dg4b"] if dg16 else w["dg4"], 4 * HP) if merged else (w["dgi"], G)
         dgh, hh_remap = (dgi, (2 * HP, HP)) if merged else (w["dgh"], None)
         # Two-range BPTT (as the forward's two ranges, the other way round): the recurrence runs from the last timestep

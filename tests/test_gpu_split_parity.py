@@ -3,7 +3,10 @@ weight-gradient GEMMs, with the engine's fused orchestration: side streams, floa
 fp32-class gates of test_gpu_parity.py, through their split instantiation PREC_SPLIT (same kernel templates, operands
 as bf16 hi + lo parts, products hi*hi + hi*lo + lo*hi; csrc/proj.hip header).  Golden vectors come from executing the
 reference notebook (oracle/make_golden.py).  Gates: loss 1e-5 .. 1e-4 relative, gradients per-tensor rel-L2 1e-4,
-parameters after N Adam steps rel-L2 1e-4 (north_star).  The GRU recurrence runs its exact fp32 kernels here."""
+parameters after N Adam steps rel-L2 1e-4 (north_star).  Since round 3 the GRU recurrence runs here through the split
+instantiation of the TIMED persistent kernel template too (gru.hip, prec 2: same work division, branch-free step, lane-swap
+re-deal, two time ranges; h and W_hh as hi + mid + lo parts, exact sigmoid / tanh), not through the generic fp32 kernels:
+`_engine` asserts it, and test_split_gru_template_vs_generic_fp32_kernels compares the two."""
 import os
 
 import numpy as np
@@ -41,6 +44,7 @@ def _engine(I):
     import svae_cf_amd as S
     eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_SPLIT)
     assert eng.fused and eng.split
+    assert eng.gru_prec == S.PREC_SPLIT, "PREC_SPLIT must run the timed GRU template, not fall back to gru_*_f32"
     return eng
 
 
@@ -181,3 +185,43 @@ def test_ml1m_shape_subset_vs_oracle():
         gd = eng.grad_dict()
         for k in O.PARAM_NAMES:
             assert _l2(gd[k].cpu().numpy(), grads_ref[k]) <= gtol, (prec, k, _l2(gd[k].cpu().numpy(), grads_ref[k]))
+
+
+def test_split_gru_template_vs_generic_fp32_kernels():
+    """The split instantiation of the persistent GRU kernels (forward in two time ranges, BPTT with the merged fp32
+    gate-gradient array) against the generic fp32 recurrence kernels of rounds 1-2 inside the same PREC_SPLIT step, on an
+    ML-20M-shaped batch with a time split: hidden states and saved gates to 2e-6 of the largest entry, every gradient
+    to 1e-5 relative L2."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    from svae_cf_amd.layout import HP
+    I, B = 20000, 256
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(2048, I, mu, sigma, lmax, seed=4321)
+    plan = None
+    for cand in synth.bucketed_batches([len(u) for u in users], B, np.random.default_rng(2)):
+        p = S.build_plan([users[i] for i in cand], 4, user_keys=cand, device="cuda", total_items=I)
+        if p.split_t > 0 and p.R % 64 != 0:
+            plan = p
+            break
+    assert plan is not None
+    got = {}
+    for generic in (False, True):
+        eng = _engine(I)
+        g = torch.Generator().manual_seed(5)
+        eng.load_state_dict({n: (torch.randn(s_, generator=g) * (0.07 if n != "item_embed.weight" else 1.0))
+                             for n, s_ in eng.layout.ref_shapes.items()})
+        if generic:
+            eng.gru_prec = S.PREC_FP32
+        eng.prepare(plan)
+        loss = float(eng.forward(plan, 0.05, seed=9, step=2)[0])
+        eng.backward()
+        torch.cuda.synchronize()
+        got[generic] = dict(loss=loss, hs=eng.ws["hs"][:plan.R * HP].clone(), g4=eng.ws["gates4"][:plan.R * HP * 4].clone(),
+                            grads={k: v.clone() for k, v in eng.grad_dict().items()})
+    a, b = got[False], got[True]
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(b["loss"])
+    for k in ("hs", "g4"):
+        assert float((a[k] - b[k]).abs().max()) <= 2e-6 * float(b[k].abs().max()), k
+    for k in b["grads"]:
+        assert _l2(a["grads"][k].cpu().numpy(), b["grads"][k].cpu().numpy()) <= 1e-5, k
