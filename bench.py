@@ -248,6 +248,8 @@ def main():
     solo = None
     if kt and eng.fused and "proj_fdh_fused" in kt and args.prec == "bf16" and world == 1 and not rehearse:
         saved = (eng.overlap, eng.time_split, eng.dw_q, eng.fdh_q0)
+        saved_wgs = eng.dw_wgs
+        eng.dw_wgs = eng._ncu                       # (flat work division: one range per CU of the idle GPU)
         # (weight-gradient sweep 3-way: 237 workgroups, one round on the idle GPU -- 4-way is 316, two rounds, 0.279 ms
         # against 0.209; the forward sweep keeps its nominal 4-way split: nominal 2 leaves unequal workgroups, 0.227
         # against 0.216)
@@ -277,6 +279,7 @@ def main():
         finally:
             eng.prof = None
             eng.overlap, eng.time_split, eng.dw_q, eng.fdh_q0 = saved
+            eng.dw_wgs = saved_wgs
             torch.cuda.synchronize()
     kt_all = dict(kt_extra)
     kt_all.update(kt)

@@ -182,6 +182,14 @@ int svae_loss_reduce(const float* nll_row, const float* kl_row, const float* w_n
 int svae_proj_nsplit(void);
 int svae_proj_ns_max(void);
 int svae_proj_schedule(int nx, int ny, int ncu, int uniform, int* sched_host, int cap, int* ns_q, int* ns_rem);
+/* FLAT work division (round 3; _fwd_dh and _bwd_dw in their bf16 instantiation): the (x tile, y tile) space, x-major,
+ * cut into nwg_want contiguous ranges of equal cost, one per workgroup; a range that crosses x-tile boundaries is run
+ * segment by segment by the same workgroup (a further segment costs `boundary` tiles' worth: 5 measured).  Writes
+ * into HOST memory `sched` (room for cap4 int4): 4 ints per segment (x tile, first y tile, end y tile, slab), the
+ * workgroups' segment offsets [nwg + 1] and the slab count of every x tile (each padded to a multiple of 4 ints).
+ * Returns the table length in int4 units, *nwg (<= nwg_want) and *nseg; the sweeps take the device copy of the table
+ * as (sched, nwg, ns_q = 0, ns_rem = nseg).  cap4 >= (nwg_want + x tiles) * 5 / 4 + 4 always suffices (x tiles = ceil(nx/256)). */
+int svae_proj_schedule_flat(int nx, int ny, int nwg_want, int boundary, int* sched_host, int cap4, int* nwg, int* nseg);
 int svae_proj_tile(void);
 int svae_proj_prep_rows(const float* h2, int R, int R_pad, void* h2b, void* h2s, void* h2tb, void* stream);
 /* rows [row0, row1) only (multiples of 32; pointers of the whole arrays) */

@@ -160,7 +160,8 @@ def install_skip(names):
 
 
 def proj_schedule(nx, ny, ncu, uniform=False):
-    """Work division of one projection sweep (svae_proj_schedule): returns (int32 numpy array [nwg, 4], ns_q, ns_rem)."""
+    """Work division of one projection sweep (svae_proj_schedule): returns (int32 numpy array [nwg, 4], nwg, ns_q,
+    ns_rem)."""
     import numpy as np
     lib = load()
     cap = lib.svae_proj_ns_max() * ((nx + 255) // 256)
@@ -172,7 +173,26 @@ def proj_schedule(nx, ny, ncu, uniform=False):
     n = fn(nx, ny, ncu, int(uniform), buf.ctypes.data, cap, _c.byref(q), _c.byref(rem))
     if n <= 0:
         raise SvaeHipError("svae_proj_schedule failed (rc=%d): %s" % (n, lib.svae_last_error().decode("utf-8", "replace")))
-    return buf[:n].copy(), q.value, rem.value
+    return buf[:n].copy(), n, q.value, rem.value
+
+
+def proj_schedule_flat(nx, ny, nwg, boundary=5):
+    """Flat work division (svae_proj_schedule_flat): returns (int32 numpy array [n4, 4] -- segments, then the
+    workgroups' segment offsets, then the slab counts --, nwg, 0, nseg): what the sweeps take as (table, nwg, ns_q,
+    ns_rem)."""
+    import numpy as np
+    lib = load()
+    xt = (nx + 255) // 256
+    cap = (int(nwg) + xt) + (int(nwg) + 4) // 4 + (xt + 3) // 4 + 4       # segments + the two tables
+    buf = np.zeros((cap, 4), dtype=np.int32)
+    w, nseg = _I(0), _I(0)
+    fn = lib.svae_proj_schedule_flat
+    fn.argtypes = [_I, _I, _I, _I, _P, _I, _c.POINTER(_I), _c.POINTER(_I)]
+    fn.restype = _I
+    n = fn(nx, ny, int(nwg), int(boundary), buf.ctypes.data, cap, _c.byref(w), _c.byref(nseg))
+    if n <= 0:
+        raise SvaeHipError("svae_proj_schedule_flat failed (rc=%d): %s" % (n, lib.svae_last_error().decode("utf-8", "replace")))
+    return buf[:n].copy(), w.value, 0, nseg.value
 
 
 

@@ -99,7 +99,9 @@ struct ProjArgs {
     float* out;                 // FWD: float2 (m, l) [NSPLIT][nx];  FDH / DW: slabs [NSPLIT][nx][160]
     float* mpart;               // FDH: [NSPLIT][nx] stabiliser of each split
     int nx, ny, ldt;
-    const int4* sched;          // per workgroup: (x tile, first y tile, end y tile, slab)
+    const int4* sched;          // per SEGMENT: (x tile, first y tile, end y tile, slab)
+    const int* wg_off;          // flat schedule: workgroup b runs segments wg_off[b] .. wg_off[b+1]-1 one after the other;
+                                // NULL: one segment per workgroup (segment = blockIdx.x)
     // split instantiation only: element distance between the parts of an image (hi at the pointer, mid = RNE(v - hi)
     // one stride further, lo = RNE(v - hi - mid) two strides further; same layout each): X's, and Y's / Y^T's
     long long xps, yps;
@@ -152,7 +154,14 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
 #ifdef SV_PROJ_TIMING
     const unsigned long long blk_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int4 sc = a.sched[blockIdx.x];
+    // Flat schedule (svae_proj_schedule_flat): a workgroup owns a contiguous range of the (x tile, y tile) space and
+    // walks it segment by segment -- at an x-tile boundary it writes its slab, takes the next rows and starts the Y
+    // pipeline again.  Every LDS read of a segment is behind its last tile's barrier, so the next segment's LDS-DMA may
+    // start at once.
+    const int seg0 = a.wg_off ? __builtin_amdgcn_readfirstlane(a.wg_off[blockIdx.x]) : (int)blockIdx.x;
+    const int seg1 = a.wg_off ? __builtin_amdgcn_readfirstlane(a.wg_off[blockIdx.x + 1]) : seg0 + 1;
+    for (int seg = seg0; seg < seg1; ++seg) {
+    const int4 sc = a.sched[seg];
     const int xt = __builtin_amdgcn_readfirstlane(sc.x), split = __builtin_amdgcn_readfirstlane(sc.w);
     const int x0 = xt * BX + wave * 32;
     const int t_begin = __builtin_amdgcn_readfirstlane(sc.y);
@@ -834,6 +843,7 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
             }
         if (MODE == MODE_FDH && lh == 0 && xok) a.mpart[(size_t)split * a.nx + x] = any_tile ? m_eff : NEG_BIG;
     }
+    }   // segments
 #ifdef SV_PROJ_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && wave == 0 && blockIdx.x < 4096) {
@@ -974,12 +984,12 @@ __global__ void proj_fdh_finish_kernel(const float* __restrict__ slabs, const fl
                                        const float* __restrict__ w_nll, int R, int K, float* __restrict__ dd1,
                                        float* __restrict__ nll_row, float* __restrict__ lse_out,
                                        unsigned short* __restrict__ h2b, int ns_q, int ns_rem,
-                                       unsigned short* __restrict__ h2b_lo) {
+                                       unsigned short* __restrict__ h2b_lo, const int* __restrict__ ns_tab) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= R) return;
     const int ln = lane < KP / 4 ? lane : 0;
-    const int ns = ns_q + ((row / BX) < ns_rem ? 1 : 0);     // wave-uniform
+    const int ns = ns_tab ? ns_tab[row / BX] : ns_q + ((row / BX) < ns_rem ? 1 : 0);     // wave-uniform
     // everything that depends on the row number only goes out first (K == 4: the targets in one 16-byte load)
     const int4 t4 = K == 4 ? *reinterpret_cast<const int4*>(tgt + (size_t)row * 4) : make_int4(-1, -1, -1, -1);
     const float w = w_nll[row];
@@ -1123,7 +1133,7 @@ __global__ __launch_bounds__(64 * DWL_WAVES) void proj_dw_finish_long_kernel(con
                                                                   const int* __restrict__ occ_row,
                                                                   const int* __restrict__ occ_items,
                                                                   float* __restrict__ gw3, float* __restrict__ gb3, int I,
-                                                                  int ns_q, int ns_rem) {
+                                                                  int ns_q, int ns_rem, const int* __restrict__ ns_tab) {
     __shared__ float4 red[DWL_WAVES][KP / 4];
     __shared__ float wred[DWL_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1132,7 +1142,7 @@ __global__ __launch_bounds__(64 * DWL_WAVES) void proj_dw_finish_long_kernel(con
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float wsum = 0.f;
     if (wave == 0) {
-        const int ns = ns_q + ((it / BX) < ns_rem ? 1 : 0);
+        const int ns = ns_tab ? ns_tab[it / BX] : ns_q + ((it / BX) < ns_rem ? 1 : 0);
         for (int z = 0; z < ns; ++z) {
             const float4 v = reinterpret_cast<const float4*>(slabs + ((size_t)z * I + it) * KP)[ln];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -1162,7 +1172,7 @@ __global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __rest
                                                              const int* __restrict__ occ_row,
                                                              const int* __restrict__ occ_items, float* __restrict__ gw3,
                                                              float* __restrict__ gb3, int nlong, int I, int I_rows,
-                                                             int ns_q, int ns_rem) {
+                                                             int ns_q, int ns_rem, const int* __restrict__ ns_tab) {
     const int lane = threadIdx.x & 63;
     const int j = nlong + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= I_rows || lane >= KP / 4) return;
@@ -1174,7 +1184,7 @@ __global__ __launch_bounds__(256) void proj_dw_finish_kernel(const float* __rest
     const int it = occ_items[j];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float wsum = 0.f;
-    const int ns = ns_q + ((it / BX) < ns_rem ? 1 : 0);      // wave-uniform
+    const int ns = ns_tab ? ns_tab[it / BX] : ns_q + ((it / BX) < ns_rem ? 1 : 0);      // wave-uniform
 #pragma unroll
     for (int z0 = 0; z0 < NS_MAX; z0 += 8) {
         float4 v[8];
@@ -1346,6 +1356,124 @@ extern "C" int svae_proj_schedule(int nx, int ny, int ncu, int uniform, int* sch
     *ns_rem = rem;
     return (int)n;
 }
+// FLAT work division (round 3; HOST function, no GPU work).  The (x tile, y tile) space of a sweep, x-major, is cut
+// into nwg contiguous ranges of equal COST, one per workgroup: a range that crosses x-tile boundaries is several
+// segments, which the workgroup runs one after the other (proj_kernel's segment loop); every segment after a
+// workgroup's first costs `boundary` tiles' worth of time on top of its tiles (slab out, rows in, the Y pipeline
+// primed again: ~8 us = 5 tiles measured).  The balanced form above cuts every x tile into q or q + 1 equal pieces:
+// its longest piece is 7 % above the mean over the bench's plans and 23 % in single launches, and that is what the
+// launch then takes.  nwg is the caller's choice (<= the CUs it wants the sweep on; capped so that no x tile gets more
+// than svae_proj_ns_max() slabs); every workgroup gets at least one tile.
+// Launch order: ranges are handed to workgroup ids so that the 32 ids of an XCD (id % 8) hold ranges whose position
+// in Y (start mod ny tiles) is adjacent -- ranges are equally long and advance at the same pace, so they stay
+// neighbours in Y for their whole length (wrapping together), and what one fetches from HBM the others find in L2.
+// Table layout (ints): 4 per segment (x tile, first y tile, end y tile, slab = ordinal of the segment within its x
+// tile) for *nseg segments in workgroup order; then wg_off [nwg + 1] padded to a multiple of 4 ints; then ns_tab
+// [x tiles] (slabs per x tile) padded likewise.  Returns the table's length in int4 units (> 0) or a negative error;
+// the sweeps take it as (sched, nwg, ns_q = 0, ns_rem = *nseg).
+extern "C" int svae_proj_schedule_flat(int nx, int ny, int nwg_want, int boundary, int* sched, int cap4, int* nwg_out,
+                                       int* nseg_out) {
+    SV_CHECK_ARG(nx > 0 && ny > 0 && nwg_want > 0 && boundary >= 0 && sched && nwg_out && nseg_out,
+                 "svae_proj_schedule_flat: bad arguments");
+    const int xt = (nx + BX - 1) / BX, nt = (ny + BY - 1) / BY;
+    const long long total = (long long)xt * nt;
+    long long W = nwg_want;
+    // at most NS_MAX segments per x tile: a range must be at least nt / (NS_MAX - 1) tiles long
+    const long long lmin = (nt + NS_MAX - 2) / (NS_MAX - 1);
+    if (W > total / lmin) W = total / lmin;
+    if (W > total) W = total;
+    if (W < 1) W = 1;
+    // greedy fill for a cost limit C: tiles until the limit is reached; binary search for the smallest C that needs <= W ranges
+    auto ranges_for = [&](double C, long long* ends) -> long long {
+        long long pos = 0, n = 0;
+        while (pos < total) {
+            double cost = 0;
+            long long p = pos;
+            while (p < total) {
+                const long long to_edge = nt - (p % nt);                 // tiles to the end of this x tile
+                const double extra = p > pos ? (double)boundary : 0.0;     // a further segment
+                if (cost + extra + 1 > C && p > pos) break;
+                long long take = (long long)(C - cost - extra);
+                if (take < 1) take = 1;
+                if (take > to_edge) take = to_edge;
+                cost += extra + (double)take;
+                p += take;
+                if (take < to_edge) break;
+            }
+            if (ends && n < W) ends[n] = p;
+            ++n;
+            pos = p;
+        }
+        return n;
+    };
+    double lo = (double)total / (double)W, hi = (double)total / (double)W + (double)boundary * (nt > 0 ? (double)total / nt / W + 2 : 2) + 2;
+    while (ranges_for(hi, nullptr) > W) hi *= 1.5;
+    for (int it = 0; it < 40; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (ranges_for(mid, nullptr) <= W) hi = mid; else lo = mid;
+    }
+    long long* ends = new long long[W];
+    const long long nr = ranges_for(hi, ends);
+    // (fewer ranges than W can come out when the limit is loose: that is then the workgroup count)
+    struct Rng { long long b, e; };
+    Rng* r = new Rng[nr];
+    for (long long i = 0; i < nr; ++i) r[i] = Rng{i ? ends[i - 1] : 0, ends[i]};
+    // workgroup order: by position in Y of the range's start, dealt to the XCDs in contiguous runs
+    long long* ord = new long long[nr];
+    for (long long i = 0; i < nr; ++i) ord[i] = i;
+    std::stable_sort(ord, ord + nr, [&](long long x, long long y) { return r[x].b % nt < r[y].b % nt; });
+    long long* of_wg = new long long[nr];
+    {
+        long long p = 0;
+        for (int c = 0; c < 8; ++c)
+            for (long long id = c; id < nr; id += 8, ++p) of_wg[id] = ord[p];
+    }
+    // slab ordinals: segments of an x tile numbered in flat order
+    long long nseg = 0;
+    for (long long i = 0; i < nr; ++i) nseg += (r[i].e - 1) / nt - r[i].b / nt + 1;
+    const long long need4 = nseg + (nr + 1 + 3) / 4 + (xt + 3) / 4;
+    if (need4 > cap4) {
+        delete[] ends; delete[] r; delete[] ord; delete[] of_wg;
+        return svae_fail(-2, "svae_proj_schedule_flat: table of %lld int4 does not fit cap %d", need4, cap4);
+    }
+    int* ns_tab = sched + 4 * nseg + 4 * ((nr + 1 + 3) / 4);
+    int* wg_off = sched + 4 * nseg;
+    for (int j = 0; j < xt; ++j) ns_tab[j] = 0;
+    // slab ordinal of the segment of range i in x tile j = number of ranges that start in x tile j before it (+1 if the
+    // x tile is entered from the range before): computed by a walk in flat order
+    int* ordinal_first = new int[nr];          // slab ordinal of each range's FIRST segment
+    {
+        for (long long i = 0; i < nr; ++i) {
+            const long long j0 = r[i].b / nt, j1 = (r[i].e - 1) / nt;
+            ordinal_first[i] = ns_tab[j0];
+            for (long long j = j0; j <= j1; ++j) ns_tab[j] += 1;
+        }
+    }
+    long long sidx = 0;
+    for (long long id = 0; id < nr; ++id) {
+        const long long i = of_wg[id];
+        wg_off[id] = (int)sidx;
+        const long long j0 = r[i].b / nt, j1 = (r[i].e - 1) / nt;
+        for (long long j = j0; j <= j1; ++j) {
+            const long long b = j == j0 ? r[i].b - j * nt : 0, e = j == j1 ? r[i].e - j * nt : nt;
+            int* o = sched + 4 * sidx++;
+            o[0] = (int)j;
+            o[1] = (int)b;
+            o[2] = (int)e;
+            o[3] = j == j0 ? ordinal_first[i] : 0;     // a range enters every further x tile at its first y tile
+        }
+    }
+    wg_off[nr] = (int)sidx;
+    for (long long k = nr + 1; k < 4 * ((nr + 1 + 3) / 4); ++k) wg_off[k] = (int)sidx;
+    for (int k = xt; k < 4 * ((xt + 3) / 4); ++k) ns_tab[k] = 0;
+    bool ok = sidx == nseg;
+    for (int j = 0; j < xt && ok; ++j) ok = ns_tab[j] >= 1 && ns_tab[j] <= NS_MAX;
+    delete[] ends; delete[] r; delete[] ord; delete[] of_wg; delete[] ordinal_first;
+    if (!ok) return svae_fail(-3, "svae_proj_schedule_flat: internal error (slab counts)");
+    *nwg_out = (int)nr;
+    *nseg_out = (int)nseg;
+    return (int)need4;
+}
 extern "C" int svae_proj_tile(void) { return BY; }
 extern "C" int svae_proj_occ_long(void) { return OCC_LONG; }
 
@@ -1403,12 +1531,17 @@ extern "C" int svae_proj_prep_items(const float* w3, const float* b3, int I, int
 // a schedule (svae_proj_schedule) must cover every x tile of nx rows exactly ns_j times: cheap consistency check
 // of the three numbers the caller hands back (a stale schedule would leave slabs unwritten)
 static bool sched_ok(int nx, int nwg, int ns_q, int ns_rem) {
-#ifdef SV_EXP_SCHED_ANY
-    return true;        // timing experiments with hand-made schedules (results wrong by construction)
-#endif
     const int xt = (nx + BX - 1) / BX;
+    if (ns_q == 0)          // flat schedule (svae_proj_schedule_flat): ns_rem = number of segments
+        return nwg >= 1 && ns_rem >= nwg && ns_rem >= xt && (long long)ns_rem <= (long long)nwg + xt;
     return ns_q >= 1 && ns_q <= NS_MAX && ns_rem >= 0 && ns_rem < xt && ns_q + (ns_rem > 0) <= NS_MAX &&
            (long long)ns_q * xt + ns_rem == nwg;
+}
+
+// Parts of a flat schedule table (ns_q == 0, ns_rem = segments): the workgroups' segment offsets and the slab counts.
+static inline const int* flat_wg_off(const int* sched, int ns_q, int nseg) { return ns_q == 0 ? sched + 4 * (long long)nseg : nullptr; }
+static inline const int* flat_ns_tab(const int* sched, int nwg, int ns_q, int nseg) {
+    return ns_q == 0 ? sched + 4 * (long long)nseg + 4 * ((nwg + 1 + 3) / 4) : nullptr;
 }
 
 // Reference interface replaced: Decoder.linear2 + F.log_softmax + likelihood of VAELoss.forward
@@ -1434,8 +1567,9 @@ extern "C" int svae_proj_nll_fwd_split(const void* h2s, const void* w3b, const f
     SV_CHECK_ARG((row_part_stride > 0) == (item_part_stride > 0) && row_part_stride >= 0,
                  "svae_proj_nll_fwd: pass both part strides or none");
     SV_CHECK_ARG(sched_ok(R, nwg, ns_q, ns_rem), "svae_proj_nll_fwd: schedule does not belong to R = %d", R);
+    SV_CHECK_ARG(ns_q > 0, "svae_proj_nll_fwd: the loss-only sweep takes the balanced schedule (svae_proj_schedule)");
     ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, nullptr, part, nullptr, R, I, 0, (const int4*)sched,
-               row_part_stride, item_part_stride};
+               nullptr, row_part_stride, item_part_stride};
     if (int e = row_part_stride > 0 ? launch_proj<MODE_FWD, true>(a, nwg, (hipStream_t)stream)
                                     : launch_proj<MODE_FWD>(a, nwg, (hipStream_t)stream)) return e;
     hipLaunchKernelGGL(proj_fwd_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream,
@@ -1463,16 +1597,18 @@ extern "C" int svae_proj_nll_fwd_dh_split(const void* h2s, void* h2b, const void
     const bool split = row_part_stride > 0;
     SV_CHECK_ARG(split == (item_part_stride > 0) && row_part_stride >= 0, "svae_proj_nll_fwd_dh: pass both part strides or none");
     SV_CHECK_ARG(sched && sched_ok(R, nwg, ns_q, ns_rem), "svae_proj_nll_fwd_dh: schedule does not belong to R = %d", R);
+    SV_CHECK_ARG(!split || ns_q > 0, "svae_proj_nll_fwd_dh: the split instantiation takes the balanced schedule");
     hipStream_t st = (hipStream_t)stream;
     if (parts & 1) {
         ProjArgs a{(const unsigned short*)h2s, (const unsigned short*)w3b, (const unsigned short*)w3tb, slabs, mpart,
-                   R, I, I_pad, (const int4*)sched, row_part_stride, item_part_stride};
+                   R, I, I_pad, (const int4*)sched, flat_wg_off(sched, ns_q, ns_rem), row_part_stride, item_part_stride};
         if (int e = split ? launch_proj<MODE_FDH, true>(a, nwg, st) : launch_proj<MODE_FDH>(a, nwg, st)) return e;
     }
     if (parts & 2) {
         hipLaunchKernelGGL(proj_fdh_finish_kernel, dim3((R + 3) / 4), dim3(256), 0, st, slabs, mpart, h2, w3, b3, tgt,
                            w_nll, R, K, dd1, nll_row, lse, (unsigned short*)h2b, ns_q, ns_rem,
-                           split ? (unsigned short*)h2b + row_part_stride : (unsigned short*)nullptr);
+                           split ? (unsigned short*)h2b + row_part_stride : (unsigned short*)nullptr,
+                           flat_ns_tab(sched, nwg, ns_q, ns_rem));
         SV_LAUNCH_CHECK();
     }
     return 0;
@@ -1507,18 +1643,20 @@ extern "C" int svae_proj_nll_bwd_dw_split(const void* w3s, const void* h2b, cons
     const bool split = row_part_stride > 0;
     SV_CHECK_ARG(split == (item_part_stride > 0) && row_part_stride >= 0, "svae_proj_nll_bwd_dw: pass both part strides or none");
     SV_CHECK_ARG(sched && sched_ok(I, nwg, ns_q, ns_rem), "svae_proj_nll_bwd_dw: schedule does not belong to I = %d", I);
+    SV_CHECK_ARG(!split || ns_q > 0, "svae_proj_nll_bwd_dw: the split instantiation takes the balanced schedule");
     hipStream_t st = (hipStream_t)stream;
     if (parts & 1) {
         ProjArgs a{(const unsigned short*)w3s, (const unsigned short*)h2b, (const unsigned short*)h2tb, slabs, nullptr,
-                   I, R, R_pad, (const int4*)sched, item_part_stride, row_part_stride};
+                   I, R, R_pad, (const int4*)sched, flat_wg_off(sched, ns_q, ns_rem), item_part_stride, row_part_stride};
         if (int e = split ? launch_proj<MODE_DW, true>(a, nwg, st) : launch_proj<MODE_DW>(a, nwg, st)) return e;
     }
     if (parts & 2) {
         if (nocc_long > 0)
             hipLaunchKernelGGL(proj_dw_finish_long_kernel, dim3(nocc_long), dim3(64 * DWL_WAVES), 0, st, slabs, h2, w_nll, occ_off,
-                               occ_row, occ_items, gw3, gb3, I, ns_q, ns_rem);
+                               occ_row, occ_items, gw3, gb3, I, ns_q, ns_rem, flat_ns_tab(sched, nwg, ns_q, ns_rem));
         hipLaunchKernelGGL(proj_dw_finish_kernel, dim3((I_rows - nocc_long + 3) / 4), dim3(256), 0, st, slabs, h2, w_nll,
-                           occ_off, occ_row, occ_items, gw3, gb3, nocc_long, I, I_rows, ns_q, ns_rem);
+                           occ_off, occ_row, occ_items, gw3, gb3, nocc_long, I, I_rows, ns_q, ns_rem,
+                           flat_ns_tab(sched, nwg, ns_q, ns_rem));
         SV_LAUNCH_CHECK();
     }
     return 0;

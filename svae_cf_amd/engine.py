@@ -165,6 +165,14 @@ class SVAEEngine:
         self._sevs = {}                # purpose -> _lib.SyncEvent, re-recorded every step
         self._sched_cache = {}         # tile-count shape -> (device table, nwg, ns_q, ns_rem), see _proj_sched
         self.dw_q = int(os.environ.get("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
+        # flat work division of the two sweeps (round 3, bf16 instantiation): equal-cost contiguous ranges of the
+        # (x tile, y tile) space, one per workgroup; SVAE_FLAT_SCHED=0 restores the balanced q / q+1 splits
+        self.flat_sched = os.environ.get("SVAE_FLAT_SCHED", "1") == "1"
+        self.flat_boundary = int(os.environ.get("SVAE_FLAT_BOUNDARY", "5"))   # cost of a further segment, in tiles
+        # workgroups of the weight-gradient sweep: it runs beside the BPTT (64 CUs) and the weight-gradient GEMMs, and
+        # what it leaves them decides the step (one box, ms per step, two rounds: 144 -> 0.863 / 0.864, 158 -> 0.851 /
+        # 0.855, 170 -> 0.922 / 0.921, 192 -> 0.932 / 0.930; balanced 2-way split = 158 workgroups: 0.859 / 0.858)
+        self.dw_wgs = int(os.environ.get("SVAE_DW_WGS", "158"))
         self.head_fused = os.environ.get("SVAE_HEAD_FUSED", "1") == "1"
         # bf16 mode: the gathered embedding rows are kept as bf16 (their two consumers -- the input-gate GEMM and the
         # input-weight gradient -- round them to bf16 anyway: bit-identical) -- half the bytes written by the gather,
@@ -649,7 +657,8 @@ class SVAEEngine:
                 _lib.call("svae_proj_nll_fwd_split", w["h2s"].data_ptr(), self.w3b.data_ptr(), w["d1"].data_ptr(),
                           self.P("decoder.linear2.weight").data_ptr(), self.P("decoder.linear2.bias").data_ptr(),
                           plan.tgt.data_ptr(), R, self.I, plan.K, w["part"].data_ptr(), w["nll_row"].data_ptr(),
-                          w["lse"].data_ptr(), *self._proj_sched(plan, "rows"), self._ps("rows"), self._ps("items"), st)
+                          w["lse"].data_ptr(), *self._proj_sched(plan, "rows", flat=False), self._ps("rows"),
+                          self._ps("items"), st)
             self._fused_grad = bool(want_grad)
             if defer_loss and want_grad and self.overlap:
                 # nothing in backward reads the scalar loss: backward() reduces it on the side stream, behind the
@@ -741,12 +750,24 @@ class SVAEEngine:
             _lib.call(name, *args, bit, _stream())
             self._toc(tag, ev)
 
-    def _proj_sched(self, plan, side, nx=None, ncu=None, host_only=False):
+    def _proj_sched(self, plan, side, nx=None, ncu=None, host_only=False, flat=None):
         """(device table, nwg, ns_q, ns_rem) of a projection sweep over this plan: 'rows' = rows resident, items
         streamed (forward / dL/dh sweep; nx = the number of rows when only a range of the plan is swept), 'items' =
-        the weight-gradient sweep.  Built once per plan and engine."""
+        the weight-gradient sweep.  Built once per plan and engine.
+        flat (default: the engine's setting, bf16 instantiation only): the flat work division of round 3
+        (svae_proj_schedule_flat: equal-cost contiguous ranges of the tile space, one per workgroup) instead of the
+        balanced one (every x tile cut into q or q + 1 pieces); the loss-only sweep of `score` always takes the latter."""
         ncu = self._ncu if ncu is None else max(8, int(ncu))
-        key = (side, self.I, ncu, nx, self.dw_q if side == "items" else self.fdh_q0)
+        flat = (self.flat_sched and not self.split) if flat is None else bool(flat)
+        if flat:
+            nwg_want = min(ncu, self.dw_wgs) if side == "items" else ncu
+            key = (side, self.I, nwg_want, nx, "flat", self.flat_boundary)
+            shape = (("rows-flat", ((plan.R if nx is None else nx) + 255) // 256, nwg_want, self.flat_boundary) if side == "rows"
+                     else ("items-flat", (plan.R + 63) // 64, nwg_want, self.flat_boundary))
+        else:
+            key = (side, self.I, ncu, nx, self.dw_q if side == "items" else self.fdh_q0)
+            shape = (("rows", ((plan.R if nx is None else nx) + 255) // 256, ncu, self.fdh_q0) if side == "rows"
+                     else ("items", (plan.R + 63) // 64, self.dw_q))
         cache = plan.proj_sched
         # A table depends on the plan only through its tile counts: x tiles of 256 rows (the forward sweep of nx
         # rows) or y tiles of 64 rows (the weight-gradient sweep of R rows).  The engine keeps every table it has
@@ -754,20 +775,24 @@ class SVAEEngine:
         # prefetcher's worker threads and holds the interpreter lock for most of its 0.15-0.25 ms -- becomes a few
         # dictionary look-ups.  (Inserted only after its upload has been enqueued: whoever finds a table there orders
         # its own work behind that copy -- the prefetcher's workers share one copy stream, the others use the caller's.)
-        shape = (("rows", ((plan.R if nx is None else nx) + 255) // 256, ncu, self.fdh_q0) if side == "rows"
-                 else ("items", (plan.R + 63) // 64, self.dw_q))
         if key not in cache and shape in self._sched_cache:
             cache[key] = self._sched_cache[shape]
         if host_only:
             if key in cache:
                 return None
         if key not in cache or host_only:
-            if side == "rows":
+            if flat:
+                # (what was measured for the workgroup counts and the boundary cost: DESIGN.md section 4, "flat schedule")
+                if side == "rows":
+                    tab, n, q, rem = _lib.proj_schedule_flat(plan.R if nx is None else nx, self.I, nwg_want, self.flat_boundary)
+                else:
+                    tab, n, q, rem = _lib.proj_schedule_flat(self.I, plan.R, nwg_want, self.flat_boundary)
+            elif side == "rows":
                 # nominal 4-way split (the workgroup count is the next whole multiple of the CU count): fewer, longer
                 # workgroups than the 8-way nominal write and re-read fewer slabs -- measured 3: 243.8k, 4: 245.0k,
                 # 5: 243.2k, 6: 242.0k, 8: 240.1k seq/s
-                tab, q, rem = _lib.proj_schedule(plan.R if nx is None else nx, self.I, ncu,
-                                                 uniform=-self.fdh_q0)
+                tab, n, q, rem = _lib.proj_schedule(plan.R if nx is None else nx, self.I, ncu,
+                                                    uniform=-self.fdh_q0)
             else:
                 # uniform 2-way split.  With the sweep on its own stream past the end of the step, fewer and longer
                 # workgroups win (slab traffic, and CUs left to the kernels beside it).  Round 1: 2: 249.4k, 3: 248.9k,
@@ -776,10 +801,10 @@ class SVAEEngine:
                 # 4: 0.945, 5: 0.959, 6: 0.949, 8: 0.967 -- at 2 the 158 workgroups leave 98 CUs to the BPTT and the
                 # weight-gradient GEMMs (0.36 -> 0.27 ms) and write half the slabs of the 4-way split.
                 fq = self.dw_q
-                tab, q, rem = _lib.proj_schedule(self.I, plan.R, ncu, uniform=1 + fq)   # (ncu unused: uniform)
+                tab, n, q, rem = _lib.proj_schedule(self.I, plan.R, ncu, uniform=1 + fq)   # (ncu unused: uniform)
             if host_only:
-                return key, tab, q, rem, shape
-            cache[key] = self._sched_cache[shape] = (torch.from_numpy(tab).to(self.device), int(tab.shape[0]), q, rem)
+                return key, tab, (n, q, rem), shape
+            cache[key] = self._sched_cache[shape] = (torch.from_numpy(tab).to(self.device), n, q, rem)
         t, n, q, rem = cache[key]
         return (t.data_ptr(), n, q, rem)
 
@@ -791,10 +816,11 @@ class SVAEEngine:
         scoring: the plan will only be scored (``score``: the loss-only sweep over all rows)."""
         if not self.fused:
             return plan
-        want = [("rows", None, None)] if scoring else [("rows", None, None), ("items", None, None)]
+        want = [("rows", None, None, False)] if scoring else [("rows", None, None, None), ("items", None, None, None)]
         if not scoring and self.time_split and plan.split_t > 0:
-            want += [("rows", plan.split_r, self._ncu - (plan.B + 3) // 4), ("rows", plan.R - plan.split_r, self._ncu)]
-        made = [m for m in (self._proj_sched(plan, sd, nx=nx, ncu=ncu, host_only=True) for sd, nx, ncu in want)
+            want += [("rows", plan.split_r, self._ncu - (plan.B + 3) // 4, None),
+                     ("rows", plan.R - plan.split_r, self._ncu, None)]
+        made = [m for m in (self._proj_sched(plan, sd, nx=nx, ncu=ncu, host_only=True, flat=fl) for sd, nx, ncu, fl in want)
                 if m is not None]
         if not made:
             return plan
@@ -806,11 +832,11 @@ class SVAEEngine:
             with _POOL_LOCK:
                 if self._pin_pool is None:
                     self._pin_pool = _PinnedPool()
-        n = sum(int(t.shape[0]) for _, t, _, _, _ in made)
+        n = sum(int(t.shape[0]) for _, t, _, _ in made)
         host = self._pin_pool.take(16 * n)
         hv = host[:16 * n].view(torch.int32).view(n, 4)
         o = 0
-        for _, t, _, _, _ in made:
+        for _, t, _, _ in made:
             hv[o:o + t.shape[0]] = torch.from_numpy(t)
             o += int(t.shape[0])
         dev = hv.to(self.device, non_blocking=True)
@@ -818,8 +844,8 @@ class SVAEEngine:
         ev.record()
         self._pin_pool.give(host, ev)
         o = 0
-        for key, t, q, rem, shape in made:
-            plan.proj_sched[key] = self._sched_cache[shape] = (dev[o:o + t.shape[0]], int(t.shape[0]), q, rem)
+        for key, t, (nwg, q, rem), shape in made:
+            plan.proj_sched[key] = self._sched_cache[shape] = (dev[o:o + t.shape[0]], nwg, q, rem)
             o += int(t.shape[0])
         return plan
 

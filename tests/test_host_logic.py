@@ -201,7 +201,8 @@ def test_proj_schedule_covers_every_tile_once(uniform):
     form launches a whole number of rounds on 256 CUs when the 16-slab cap does not bind."""
     from svae_cf_amd import _lib
     for nx, ny in ((21814, 20000), (20000, 21814), (300, 97), (97, 300), (2957, 20000), (50944, 20000), (257, 63), (1, 1)):
-        tab, q, rem = _lib.proj_schedule(nx, ny, 256, uniform)
+        tab, nwg, q, rem = _lib.proj_schedule(nx, ny, 256, uniform)
+        assert nwg == len(tab)
         xt, nt = (nx + 255) // 256, (ny + 63) // 64
         cov = np.zeros((xt, nt), dtype=np.int64)
         for j, b, e, s in tab:
@@ -218,6 +219,43 @@ def test_proj_schedule_covers_every_tile_once(uniform):
             assert len(tab) % 256 == 0
         ln = tab[:, 2] - tab[:, 1]
         assert ln.max() - ln.min() <= nt // q - nt // (q + 1) + 1
+
+
+@pytest.mark.parametrize("boundary", [0, 5])
+def test_flat_proj_schedule_covers_every_tile_once_at_equal_cost(boundary):
+    """svae_proj_schedule_flat (round 3): contiguous ranges of the x-major (x tile, y tile) space, one per workgroup:
+    every tile pair belongs to exactly one segment, an x tile's slabs are 0..ns_j-1 with ns_j <= 16 and equal to the
+    table's slab counts, the workgroups' segment lists partition the segments in order, every workgroup has work, and
+    -- the point of it -- no workgroup's cost (tiles + `boundary` per further segment) exceeds the mean by more than a
+    tile and a boundary (the balanced form's longest piece: up to 23 % above the mean)."""
+    from svae_cf_amd import _lib
+    nsm = _lib.load().svae_proj_ns_max()
+    for nx, ny, want in ((21814, 20000, 256), (15000, 20000, 192), (6800, 20000, 256), (20000, 21814, 192),
+                         (20000, 21814, 158), (300, 20000, 256), (50769, 20000, 256), (97, 300, 256), (257, 63, 7),
+                         (1, 1, 256), (1000000, 11200, 256), (11200, 1000000, 256)):
+        tab, w, q, nseg = _lib.proj_schedule_flat(nx, ny, want, boundary)
+        xt, nt = (nx + 255) // 256, (ny + 63) // 64
+        assert q == 0 and 1 <= w <= want and w <= nseg <= w + xt
+        flat = tab.reshape(-1)
+        seg = tab[:nseg]
+        off = flat[4 * nseg:4 * nseg + w + 1]
+        ns = flat[4 * nseg + 4 * ((w + 1 + 3) // 4):][:xt]
+        cov = np.zeros((xt, nt), dtype=np.int64)
+        for j, b, e, _ in seg:
+            assert 0 <= b < e <= nt
+            cov[j, b:e] += 1
+        assert (cov == 1).all(), (nx, ny)
+        assert ns.min() >= 1 and ns.max() <= nsm
+        for j in range(xt):
+            assert sorted(seg[seg[:, 0] == j][:, 3].tolist()) == list(range(ns[j]))
+        assert off[0] == 0 and off[w] == nseg and (np.diff(off) >= 1).all()
+        ln = seg[:, 2] - seg[:, 1]
+        cost = np.array([ln[off[i]:off[i + 1]].sum() + boundary * (off[i + 1] - off[i] - 1) for i in range(w)])
+        assert cost.max() <= cost.sum() / w + 1 + boundary, (nx, ny, cost.max(), cost.mean())
+        # a workgroup's segments are consecutive in the flat order: next x tile, from its first y tile
+        for i in range(w):
+            for k in range(off[i] + 1, off[i + 1]):
+                assert seg[k][0] == seg[k - 1][0] + 1 and seg[k][1] == 0 and seg[k - 1][2] == nt
 
 
 def _free_port():
