@@ -378,9 +378,6 @@ constexpr int WLF_ELEMS = 6 * WL_FRAGS * 64 * 8;
 constexpr int FWD_WAVES = 8;
 constexpr int XS_FLOATS = 2 * 3 * 64;              // re-deal scratch of one wave: [tile][gate][user][unit]
 
-#ifndef SV_GRU_ALT
-#define SV_GRU_ALT 1
-#endif
 // SPLIT: the parity instantiation of the SAME recurrence kernel (prec 2, used by PREC_SPLIT): same work division
 // (MU users per workgroup, 8 waves, wave w owns hidden tiles w and w + 8, lane 16 u + n owns user u of unit n), same
 // branch-free step (out-of-range buffer offsets for inactive users, input gates fetched one step ahead, accumulator rows
@@ -396,7 +393,7 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
     const int ln = lane & 15, lk = lane >> 4;
     constexpr int KS = SV_HP / 32;  // 7 k-steps
     constexpr int NL = SPLIT ? 0 : NQ - 1;      // tiles in LDS
-    constexpr bool ALT = SV_GRU_ALT != 0 && !SPLIT;
+    constexpr bool ALT = !SPLIT;          // per-tile alternation (below)
     constexpr int HIMG = 2 * MB * HLDB;          // elements of one ping-pong h image pair
     unsigned short* const h_mid = w_lds;         // (SPLIT only)
     unsigned short* const h_lo = w_lds + HIMG;
@@ -658,7 +655,6 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
             if (lk < MU) hnxt[lk * HLDB + j] = sv_f2bf(hn);
         }
         SV_TS(4)
-#ifndef SV_EXP_NOSTORE
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s_hn[q]), hs_b, ohs + 512 * q, 0, 0);
@@ -666,7 +662,6 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
             const f32x4 g0 = {s_rg[q], s_zg[q], s_ng[q], gh[q][2]};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, g0), g4_b, og4 + 2048 * q, 0, 0);
         }
-#endif
         SV_TS(5)
         na = na_next;
         rbase = rbase_next;

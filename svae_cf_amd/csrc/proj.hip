@@ -81,8 +81,6 @@ constexpr int C_ONE = 150, C_BH = 151, C_BL = 152, C_RH = 153, C_RL = 154, C_MH 
 constexpr int YIMG_BYTES = BY * KP * 2;        // 20480
 constexpr int TIMG_BYTES = KP * BY * 2;        // 20480
 constexpr int STAGE_BYTES = YIMG_BYTES + TIMG_BYTES;
-constexpr int NCHUNK = YIMG_BYTES / 16;        // 1280 chunks per image
-constexpr int NSTAGE = 3;                      // loss-only sweep (FWD) and the split instantiation's three parts
 constexpr int NSTAGE_P = 4;                    // software-pipelined sweeps (FDH / DW): the whole 160 KiB of the CU
 constexpr int LDS_BYTES = NSTAGE_P * STAGE_BYTES;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -457,11 +455,7 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
             const bool dma = j + DAH < ntile;             // tile j+DAH is issued during this tile's iterations
             const char* dy = Yg + (size_t)(t_begin + j + DAH) * (BY * KP * 2);
             char* dl = smem + sd * PSTAGE + wave * 1024;
-#ifdef SV_EXP_NODMA      // timing experiment only (wrong results): no LDS-DMA inside the loop
-#define SV_DMA(q_) {}
-#else
 #define SV_DMA(q_) if (dma && (q_) < npc) SV_PIECE1(q_, dy, dl)
-#endif
             SV_WSTAMP(0)
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -477,9 +471,7 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                         //  two phases, and W divides 2 KS1, not KS1)
                         const int sl = (KS1 * sub + s) % W;
                         c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sl], xf[s], c1, 0, 0, 0);
-#ifndef SV_EXP_NOFA
                         fa[sl] = s + W < KS1 ? SV_YA(a1, 1 - sub, s + W) : SV_YA(stn, sub, s + W - KS1);
-#endif
                         SV_MFMA_DS
                         if (s == 2) SV_DMA(sub)
                         if (sub == 0 && s == 6) SV_DMA(2)
@@ -500,11 +492,7 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                     // "rewrites" a gap's inputs (the MFMA's A operand, the two logits) and the gap before's output is
                     // a point they cannot cross.  It emits no instruction.  (Literal gap numbers: the transposed
                     // reads take their offsets as immediates.)
-#ifdef SV_EXP_NOEXP      // timing experiment only (wrong results): no v_exp_f32
-#define SV_EXP2(x_) (x_)
-#else
 #define SV_EXP2(x_) __builtin_amdgcn_exp2f(x_)
-#endif
 #define SV_B_PIN(i_)                                                                                          \
     if ((i_) == 0) asm volatile("" : "+v"(pa[0]));                                                            \
     else if ((i_) == 1) asm volatile("" : "+v"(pa[1]), "+v"(c1[0]), "+v"(c1[1]));                             \
@@ -512,26 +500,18 @@ __global__ __launch_bounds__(512, 1) void proj_kernel(ProjArgs a) {
                                           : "v"(pw[(i_) >= 2 ? (i_) - 2 : 0]));                               \
     else asm volatile("" : "+v"(pa[(i_) & 1]) : "v"(pw[7]));
 #define SV_SL(sub_, i_) ((KS1 * (sub_) + (i_)) % W)       /* window slot, as in phase A */
-#ifdef SV_EXP_NOVALU     /* timing builds only (wrong results): no vector work / no transposed reads in the gaps */
-#define SV_GAP_VALU 0
-#else
-#define SV_GAP_VALU 1
-#endif
-#ifdef SV_EXP_NOTR
-#define SV_GAP_TR 0
-#else
-#define SV_GAP_TR 1
-#endif
+    /* (The timing builds that stripped this loop -- no LDS-DMA, no fragment reads, no exponentials, no vector work: wrong
+        results by construction, figures in the comment above SV_TILE_SYNC -- are in the history of this file, round 2;  
+        the production translation unit carries none of them.) */
 #define SV_B_GAP(sub_, i_)                                                                                    \
     {                                                                                                         \
         SV_B_PIN(i_)                                                                                          \
         asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fb[SV_SL(sub_, i_)]));                                     \
         Z[(i_) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[(i_) & 1], fb[SV_SL(sub_, i_)], Z[(i_) >> 1], 0, 0, 0); \
-        if (!SV_GAP_TR) {}                                                                                    \
-        else if ((i_) + W < KS1) fb[SV_SL(sub_, i_)] = SV_YB(tst, sub_, ((i_) + W) % KS1);                    \
+        if ((i_) + W < KS1) fb[SV_SL(sub_, i_)] = SV_YB(tst, sub_, ((i_) + W) % KS1);                    \
         else if ((sub_) == 0) fb[SV_SL(sub_, i_)] = SV_YB(tst, 1, ((i_) + W) % KS1);                          \
         else fb[SV_SL(sub_, i_)] = SV_YB(tsn, 0, ((i_) + W) % KS1);                                           \
-        if (SV_GAP_VALU && (i_) >= 1 && (i_) <= 8) {                                                          \
+        if ((i_) >= 1 && (i_) <= 8) {                                                          \
             const float l0_ = c1[2 * (i_) - 2], l1_ = c1[2 * (i_) - 1];                                       \
             pw[(i_) - 1] = pack_bf16(SV_EXP2(l0_), SV_EXP2(l1_));                                             \
             /* one v_max3_f32 (fmaxf() also quiets NaNs: two more instructions per logit) */                  \

@@ -69,6 +69,19 @@ class _Launch:
         return False
 
 
+# Tuning switches of the step's order and work division.  Every default is the measured optimum (the comments beside
+# the attributes say what was measured); the environment is consulted ONLY when SVAE_TUNING=1 is set as well -- the A/B
+# tools under tools/ set it -- so that a stray SVAE_* variable in a training environment cannot steer the product path.
+# ``python -c "import svae_cf_amd.engine as e; print(e.ENGINE_OPTIONS)"`` after constructing an engine lists them.
+ENGINE_OPTIONS = {}
+_TUNING = os.environ.get("SVAE_TUNING", "0") == "1"
+
+
+def _opt(name, default):
+    ENGINE_OPTIONS[name] = default
+    return os.environ.get(name, default) if _TUNING else default
+
+
 class SVAEEngine:
     def __init__(self, total_items, device="cuda", prec=PREC_FP32, lr=1e-3, betas=(0.9, 0.999),
                  adam_eps=1e-8, weight_decay=5e-3):
@@ -78,14 +91,14 @@ class SVAEEngine:
         self.device = torch.device(device)
         with torch.cuda.device(self.device):
             _lib.call("svae_check_device")
-        self._ncu = int(os.environ.get("SVAE_PROJ_CUS", torch.cuda.get_device_properties(self.device).multi_processor_count))
+        self._ncu = int(_opt("SVAE_PROJ_CUS", torch.cuda.get_device_properties(self.device).multi_processor_count))
         self.layout = ParamLayout(total_items)
         self.I, self.IP = self.layout.I, self.layout.IP
         self.prec = prec
         self.split = prec == PREC_SPLIT
         # PREC_SPLIT runs the recurrence through the split instantiation of the TIMED kernel template (gru.hip, prec 2)
         # since round 3; SVAE_SPLIT_GRU_F32=1 restores the generic fp32 kernels of rounds 1-2 in that mode
-        self.gru_prec = PREC_FP32 if (self.split and os.environ.get("SVAE_SPLIT_GRU_F32", "0") == "1") else prec
+        self.gru_prec = PREC_FP32 if (self.split and _opt("SVAE_SPLIT_GRU_F32", "0") == "1") else prec
         self.gemm_prec = PREC_FP32 if self.split else prec         # generic GEMM (dense surface): fp32 or bf16
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
         n = self.layout.total
@@ -107,7 +120,7 @@ class SVAEEngine:
         self.ws = {}
         # row splits of the weight-gradient GEMMs (end of round 2, tools/sweep_env.sh, ms per step on one box, two
         # rounds: 32 -> 0.868 / 0.870, 16 -> 0.867 / 0.870, 24 -> 0.868 / 0.869, 21 -> 0.881 / 0.879, 48 -> 0.883 / 0.881)
-        self.nsplit = int(os.environ.get("SVAE_NSPLIT", "32"))
+        self.nsplit = int(_opt("SVAE_NSPLIT", "32"))
         self.slabs = torch.zeros(self.nsplit * (G * E + G), **f32)        # largest split-K output: dW_ih
         self.slabs_side = torch.zeros(self.nsplit * (DP * HP + DP), **f32)  # side-stream weight gradients
         # dW_hh's own slabs: the paired launch of the two GRU weight gradients (and the two-range BPTT) keep them
@@ -135,51 +148,51 @@ class SVAEEngine:
         self._dtmp_extra = None
         self._loss_deferred = False
         self._train_stream = None
-        self.wgrad_pair = os.environ.get("SVAE_WGRAD_PAIR", "1") == "1"   # the two GRU weight gradients in one launch
+        self.wgrad_pair = _opt("SVAE_WGRAD_PAIR", "1") == "1"   # the two GRU weight gradients in one launch
         # stream priorities of the side stream and of the decoder.linear2 stream ("a,b"; lower number = higher priority,
         # 0 = the default, the caller's stream is whatever the caller made it)
-        self.side_prio = [int(x) for x in os.environ.get("SVAE_SIDE_PRIO", "0,0").split(",")]
-        self.time_split = os.environ.get("SVAE_TIME_SPLIT", "1") == "1"
-        self.rowgemm = os.environ.get("SVAE_ROWGEMM", "1") == "1"
-        self.merged_dg = os.environ.get("SVAE_MERGED_DG", "1") == "1"
-        self.dg_bf16 = os.environ.get("SVAE_DG_BF16", "1") == "1"
+        self.side_prio = [int(x) for x in _opt("SVAE_SIDE_PRIO", "0,0").split(",")]
+        self.time_split = _opt("SVAE_TIME_SPLIT", "1") == "1"
+        self.rowgemm = _opt("SVAE_ROWGEMM", "1") == "1"
+        self.merged_dg = _opt("SVAE_MERGED_DG", "1") == "1"
+        self.dg_bf16 = _opt("SVAE_DG_BF16", "1") == "1"
         # train_step only: the decoder.linear2 gradient work (weight-gradient sweep, its finish, the bucket's
         # all-reduce, Adam over the bucket, the bf16 operand copies of the new weights) runs on a stream of its own
         # and the step does not wait for it -- it finishes under the next step's embedding / input GEMM / first
         # recurrence range, which leave most of the GPU idle, and the next step waits for it before its decoder side
-        self.float_w3 = os.environ.get("SVAE_FLOAT_W3", "1") == "1"
-        self.fused_prep = os.environ.get("SVAE_FUSED_PREP", "1") == "1" and not self.split
+        self.float_w3 = _opt("SVAE_FLOAT_W3", "1") == "1"
+        self.fused_prep = _opt("SVAE_FUSED_PREP", "1") == "1" and not self.split
         self._in_step = False
         self._float_pending = False
         self._float_plan = None
         self._w3_event = None          # recorded on the w3 stream behind the floated work of the last train_step
         self._w3_fresh = False         # w3b / w3s / w3tb match the current parameters (made by the floated work)
-        self.tail_embedding_first = os.environ.get("SVAE_TAIL", "emb") == "emb"
-        self.gru_wgrad_side = os.environ.get("SVAE_GRU_WGRAD_SIDE", "1") == "1"
-        self.gi_split = os.environ.get("SVAE_GI_SPLIT", "1") == "1"
-        self.bptt_split = os.environ.get("SVAE_BPTT_SPLIT", "0") == "1"
+        self.tail_embedding_first = _opt("SVAE_TAIL", "emb") == "emb"
+        self.gru_wgrad_side = _opt("SVAE_GRU_WGRAD_SIDE", "1") == "1"
+        self.gi_split = _opt("SVAE_GI_SPLIT", "1") == "1"
+        self.bptt_split = _opt("SVAE_BPTT_SPLIT", "0") == "1"
         # (both split counts re-swept on the round's final step, tools/sweep_env.sh, ms per step on one box, two rounds:
         #  forward 3 -> 0.864, 4 -> 0.864, 5 -> 0.870, 6 -> 0.872, 8 -> 0.883; weight gradient 2 -> 0.866, 3 -> 0.924,
         #  4 -> 0.911)
-        self.fdh_q0 = int(os.environ.get("SVAE_FDH_Q0", "4"))  # nominal split count of the forward sweep (_proj_sched)
+        self.fdh_q0 = int(_opt("SVAE_FDH_Q0", "4"))  # nominal split count of the forward sweep (_proj_sched)
         self._sevs = {}                # purpose -> _lib.SyncEvent, re-recorded every step
         self._sched_cache = {}         # tile-count shape -> (device table, nwg, ns_q, ns_rem), see _proj_sched
-        self.dw_q = int(os.environ.get("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
+        self.dw_q = int(_opt("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
         # flat work division of the two sweeps (round 3, bf16 instantiation): equal-cost contiguous ranges of the
         # (x tile, y tile) space, one per workgroup; SVAE_FLAT_SCHED=0 restores the balanced q / q+1 splits
-        self.flat_sched = os.environ.get("SVAE_FLAT_SCHED", "1") == "1"
-        self.flat_boundary = int(os.environ.get("SVAE_FLAT_BOUNDARY", "5"))   # cost of a further segment, in tiles
+        self.flat_sched = _opt("SVAE_FLAT_SCHED", "1") == "1"
+        self.flat_boundary = int(_opt("SVAE_FLAT_BOUNDARY", "5"))   # cost of a further segment, in tiles
         # workgroups of the weight-gradient sweep: it runs beside the BPTT (64 CUs) and the weight-gradient GEMMs, and
         # what it leaves them decides the step (one box, ms per step, two rounds: 144 -> 0.863 / 0.864, 158 -> 0.851 /
         # 0.855, 170 -> 0.922 / 0.921, 192 -> 0.932 / 0.930; balanced 2-way split = 158 workgroups: 0.859 / 0.858)
-        self.dw_wgs = int(os.environ.get("SVAE_DW_WGS", "158"))
-        self.head_fused = os.environ.get("SVAE_HEAD_FUSED", "1") == "1"
+        self.dw_wgs = int(_opt("SVAE_DW_WGS", "158"))
+        self.head_fused = _opt("SVAE_HEAD_FUSED", "1") == "1"
         # bf16 mode: the gathered embedding rows are kept as bf16 (their two consumers -- the input-gate GEMM and the
         # input-weight gradient -- round them to bf16 anyway: bit-identical) -- half the bytes written by the gather,
         # read by the GEMM and re-read six times from L2 by the weight-gradient kernel
-        self.emb16 = os.environ.get("SVAE_EMB16", "1") == "1"
-        self.mlp2_side = os.environ.get("SVAE_MLP2_SIDE", "1") == "1"
-        self.early_embed_opt = os.environ.get("SVAE_EARLY_EMBED_OPT", "0") == "1"
+        self.emb16 = _opt("SVAE_EMB16", "1") == "1"
+        self.mlp2_side = _opt("SVAE_MLP2_SIDE", "1") == "1"
+        self.early_embed_opt = _opt("SVAE_EARLY_EMBED_OPT", "0") == "1"
         self._early_opt = None         # train_step -> backward: (range, gscale, step number) of the embedding bucket
         self.grad_sync = None          # dist.GradSync for data parallel runs
         self.event_pool = []
@@ -330,7 +343,7 @@ class SVAEEngine:
         whatever stream is current -- but the caller's chain is the step's critical path and competes for CUs with
         the engine's own side streams: at high priority the step measured 0.24 % shorter (0.8497 -> 0.8477 ms, three
         alternating pairs).  ``SVAE_TRAIN_HIPRIO=0``: the current stream."""
-        if os.environ.get("SVAE_TRAIN_HIPRIO", "1") != "1":
+        if _opt("SVAE_TRAIN_HIPRIO", "1") != "1":
             return torch.cuda.current_stream(self.device)
         if self._train_stream is None:
             key = self._dev_index()

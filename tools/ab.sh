@@ -2,6 +2,7 @@
 # A/B of two builds of the kernel library on one box: bench.py with the in-tree library and with SVAE_HIP_LIB=$1,
 # alternating, $2 rounds.  Usage (via gpurun): bash tools/ab.sh svae_cf_amd/csrc/exp/lib_base.so 2 [bench args]
 set -o pipefail
+export SVAE_TUNING=1      # the engine reads its SVAE_* tuning switches only with this set (engine.py, ENGINE_OPTIONS)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT" || exit 1
 ALT=$1; N=${2:-2}; shift 2

@@ -2,6 +2,7 @@
 # A/B of one environment switch on one box: bench.py with VAR=A and VAR=B, alternating, N rounds.
 # Usage (via gpurun): bash tools/ab_env.sh SVAE_LOSS_LATE 1 0 3 [bench args]
 set -o pipefail
+export SVAE_TUNING=1      # the engine reads its SVAE_* tuning switches only with this set (engine.py, ENGINE_OPTIONS)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT" || exit 1
 VAR=$1; A=$2; B=$3; N=${4:-2}; shift 4

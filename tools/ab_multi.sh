@@ -1,6 +1,7 @@
 #!/bin/bash
 # Alternating A/B/C.. of environment settings on one box: bash tools/ab_multi.sh N "VAR=a VAR2=b" "VAR=c" ... -- [bench args]
 set -o pipefail
+export SVAE_TUNING=1      # the engine reads its SVAE_* tuning switches only with this set (engine.py, ENGINE_OPTIONS)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT" || exit 1
 N=$1; shift

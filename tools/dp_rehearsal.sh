@@ -6,6 +6,7 @@
 #  2. gloo leg: 2 ranks share the card, gradients staged through host memory: launch contract, balanced
 #     sharding, matched collectives, rank-0 JSON line.  Its throughput means nothing.
 set -o pipefail
+export SVAE_TUNING=1      # the engine reads its SVAE_* tuning switches only with this set (engine.py, ENGINE_OPTIONS)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT" || exit 1
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SVAE_TUNING=1      # the engine reads its SVAE_* tuning switches only with this set (engine.py, ENGINE_OPTIONS)
 # experiment: forced split counts of the weight-gradient sweep
 cd ${GRAFT_REPO_ROOT:-.}
 for q in 3 4 6 8 9 12 16; do

@@ -17,7 +17,7 @@ PASS[fetch]="FETCH_SIZE TCC_HIT_sum"
 PASS[write]="WRITE_SIZE TCC_MISS_sum TCC_REQ_sum"
 : > "$ROOT/gpurun_out/pmc_$TAG.txt"
 for p in sq1 sq2 fetch write; do
-    timeout -s KILL 150 rocprofv3 --pmc ${PASS[$p]} --output-format csv -d "$OUT/$p" -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline > "$OUT/$p.log" 2>&1
+    timeout -s KILL 150 rocprofv3 --pmc ${PASS[$p]} --output-format csv -d "$OUT/$p" -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-fp32-class --no-cold-figure > "$OUT/$p.log" 2>&1
     rc=$?
     if [ $rc -ne 0 ]; then echo "pass $p failed rc=$rc"; tail -5 "$OUT/$p.log"; exit 1; fi
     f=$(ls "$OUT/$p"/*/*counter_collection.csv | tail -1)

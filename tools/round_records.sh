@@ -2,6 +2,7 @@
 # The round's secondary records in one GPU call (each step under its own time limit, chain stops at a failure):
 #   gpurun --timeout 1100 -- 'bash tools/round_records.sh <tag>'
 set -o pipefail
+export SVAE_TUNING=1      # the engine reads its SVAE_* tuning switches only with this set (engine.py, ENGINE_OPTIONS)
 TAG=${1:-x}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out

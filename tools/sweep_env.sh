@@ -1,6 +1,7 @@
 #!/bin/bash
 # One environment switch over several values on one box, N rounds: bash tools/sweep_env.sh VAR N v1 v2 v3 ...
 set -o pipefail
+export SVAE_TUNING=1      # the engine reads its SVAE_* tuning switches only with this set (engine.py, ENGINE_OPTIONS)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT" || exit 1
 VAR=$1; N=$2; shift 2

@@ -2,6 +2,7 @@
 # Per-launch durations of the two projection sweeps inside the step, from a rocprofv3 kernel trace of the bench, for
 # SVAE_FLAT_SCHED = 1 and 0 (one box, one call).  Usage (via gpurun): bash tools/sweep_trace.sh <tag>
 set -o pipefail
+export SVAE_TUNING=1      # the engine reads its SVAE_* tuning switches only with this set (engine.py, ENGINE_OPTIONS)
 TAG=${1:-x}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
