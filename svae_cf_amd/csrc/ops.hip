@@ -457,6 +457,9 @@ constexpr int TOPK_NCAND = 4096;
 constexpr int TOPK_RV4 = 6;                // float4 per thread of the register-resident row: 24 576 items
 constexpr int TOPK_MASKW = 4096;           // 131 072 items
 
+// STREAM: the instantiation for catalogues beyond 24 576 items (the streamed path below; 82 registers, one workgroup per
+// CU); the other one keeps the 50 registers that let two workgroups share a CU.
+template <bool STREAM>
 __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restrict__ scores, int ld,
                                                             const int* __restrict__ seen, const int* __restrict__ seen_off,
                                                             int I, int K, int* __restrict__ out_idx,
@@ -478,34 +481,78 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
     const float* s = scores + (size_t)u * ld;
     int* oi = out_idx + (size_t)u * K;
     float* ov = out_val + (size_t)u * K;
-    // The masked row: with the seen items as a bit set in LDS it is computed on the fly from the scores (no masked
-    // copy in HBM: half of the kernel's traffic and one pass less); larger catalogues keep the copy in `work`.
-    const bool lds_mask = I <= 32 * TOPK_MASKW;          // uniform
-    if (lds_mask) {
-        for (int i = tid; i < (I + 31) / 32; i += 1024) maskw[i] = 0u;
+    // Three ways to the candidate list, by catalogue size (all uniform decisions):
+    //   in_regs   I <= 24 576: the row is read ONCE, 16 bytes per lane, and stays in registers as sort keys; the seen
+    //             items are a bit set in LDS;
+    //   streamed  larger catalogues (round 3): the row is still read ONCE, in register-resident chunks of 24 576 items
+    //             with the next chunk's loads in flight; the seen items are a small hash set in LDS that is only asked
+    //             about the few scores that reach the running bound (masking can only LOWER a score), the bound is
+    //             tightened by selecting over the candidate list whenever that fills up;
+    //   legacy    anything else (unaligned rows, more than 1024 - K seen items, a flood of ties): the masked row through
+    //             the LDS bit set (up to 131 072 items) or a copy in `work`, read twice with 4-byte loads.
+    const int nseen = seen_off[u + 1] - seen_off[u];
+    const bool aligned = (ld & 3) == 0 && ((uintptr_t)scores & 15) == 0;
+    const bool in_regs = K <= TOPK_CAP && I <= 32 * TOPK_MASKW && I <= 4096 * TOPK_RV4 && aligned;
+    bool streamed = STREAM && K <= TOPK_CAP && !in_regs && aligned && I >= 4096 * TOPK_RV4 && nseen >= 0 && K + nseen <= 1024;
+    bool lds_mask = I <= 32 * TOPK_MASKW;
+    int* const hset = reinterpret_cast<int*>(maskw);      // streamed: 2048-slot open-addressing set of the seen items
+    auto is_seen = [&](int it) -> bool {
+        unsigned h = ((unsigned)it * 2654435761u) >> 21;
+        for (;;) {
+            const int e = hset[h & 2047];
+            if (e == it) return true;
+            if (e < 0) return false;
+            ++h;
+        }
+    };
+    // (legacy / in_regs) the masked row: with the seen items as a bit set in LDS it is computed on the fly from the
+    // scores (no masked copy in HBM); catalogues beyond 131 072 items keep the copy in `work`.
+    auto mask_setup = [&]() {
+        if (lds_mask) {
+            for (int i = tid; i < (I + 31) / 32; i += 1024) maskw[i] = 0u;
+            __syncthreads();
+            for (int i = seen_off[u] + tid; i < seen_off[u + 1]; i += 1024) {
+                const int it = seen[i];
+                if (it >= 0 && it < I) atomicOr(&maskw[it >> 5], 1u << (it & 31));
+            }
+        } else {
+            for (int i = tid; i < I; i += 1024) w[i] = s[i];
+            __syncthreads();
+            for (int i = seen_off[u] + tid; i < seen_off[u + 1]; i += 1024) {
+                const int it = seen[i];
+                if (it >= 0 && it < I) { const float v = s[it]; w[it] = v - fabsf(v * 1.0f) * 100000000.0f; }
+            }
+        }
+        __syncthreads();
+    };
+    if (streamed) {
+        for (int i = tid; i < 2048; i += 1024) hset[i] = -1;
         __syncthreads();
         for (int i = seen_off[u] + tid; i < seen_off[u + 1]; i += 1024) {
             const int it = seen[i];
-            if (it >= 0 && it < I) atomicOr(&maskw[it >> 5], 1u << (it & 31));
+            if (it >= 0 && it < I) {
+                unsigned h = ((unsigned)it * 2654435761u) >> 21;
+                for (;;) {
+                    const int old = atomicCAS(&hset[h & 2047], -1, it);
+                    if (old == -1 || old == it) break;
+                    ++h;
+                }
+            }
         }
     } else {
-        for (int i = tid; i < I; i += 1024) w[i] = s[i];
-        __syncthreads();
-        for (int i = seen_off[u] + tid; i < seen_off[u + 1]; i += 1024) {
-            const int it = seen[i];
-            if (it >= 0 && it < I) { const float v = s[it]; w[it] = v - fabsf(v * 1.0f) * 100000000.0f; }
-        }
+        mask_setup();
     }
     if (tid == 0) { s_ngt = 0; s_nties = 0; s_ncand = 0; }
     __syncthreads();
     auto val = [&](int i) -> float {
+        if (streamed) { const float v = s[i]; return is_seen(i) ? v - fabsf(v * 1.0f) * 100000000.0f : v; }
         if (!lds_mask) return w[i];
         const float v = s[i];
         return ((maskw[i >> 5] >> (i & 31)) & 1u) ? v - fabsf(v * 1.0f) * 100000000.0f : v;
     };
     // the rare paths below (K beyond the cap, a flood of ties) work on the materialised row
     auto materialise = [&]() {
-        if (lds_mask) {
+        if (lds_mask || streamed) {
             for (int i = tid; i < I; i += 1024) w[i] = val(i);
             __syncthreads();
         }
@@ -518,10 +565,103 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
     // ---- pre-filter.  The K-th largest of the 1024 per-thread maxima is a lower bound of the K-th largest score
     // (at least K scores reach it), and with scores dealt to threads in small runs only a few hundred do: the exact
     // selection then runs over those in LDS instead of histogramming every score four times.
-    // Catalogues up to 4096 * TOPK_RV4 items: the row is read from HBM ONCE, 16 bytes per lane, and stays in registers
-    // (as sort keys, seen items already pushed down) for both passes -- before, the maxima pass and the filter pass
-    // each read it with 4-byte loads (the second time from L2).
-    const bool in_regs = lds_mask && I <= 4096 * TOPK_RV4 && (ld & 3) == 0 && ((uintptr_t)scores & 15) == 0;   // uniform
+    if constexpr (STREAM) if (streamed) {
+        // Chunk c = items [c CH, (c+1) CH); thread t holds float4 number t + 1024 j of it, j < TOPK_RV4.
+        constexpr int CH = 4096 * TOPK_RV4;
+        const int nchunk = (I + CH - 1) / CH;
+        float4 cur[TOPK_RV4], nxt[TOPK_RV4];
+        auto load_chunk = [&](int c, float4* dst) {
+#pragma unroll
+            for (int j = 0; j < TOPK_RV4; ++j) {
+                const int i4 = c * CH + 4 * (tid + 1024 * j);
+                dst[j] = i4 < I ? *reinterpret_cast<const float4*>(s + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        load_chunk(0, cur);
+        unsigned bound = 0u;
+        bool overflow = false;
+        for (int c = 0; c < nchunk; ++c) {
+            if (c + 1 < nchunk) load_chunk(c + 1, nxt);
+            if (c == 0) {
+                // the first chunk sets the bound: the (K + nseen)-th largest of the threads' RAW maxima -- at most nseen
+                // of the maxima above it belong to seen items, so at least K unseen scores reach it
+                unsigned m = 0u;
+#pragma unroll
+                for (int j = 0; j < TOPK_RV4; ++j) {
+                    const int i4 = 4 * (tid + 1024 * j);
+                    const float e[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned k = i4 + q < I ? topk_key(e[q]) : 0u;
+                        m = k > m ? k : m;
+                    }
+                }
+                tk[tid] = m;
+                __syncthreads();
+                topk_radix_select([&](int i) { return tk[i]; }, 1024, K + nseen, hist, &s_prefix, &s_remaining);
+                bound = s_prefix;
+            }
+#pragma unroll
+            for (int j = 0; j < TOPK_RV4; ++j) {
+                const int i4 = c * CH + 4 * (tid + 1024 * j);
+                const float e[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = i4 + q;
+                    if (i < I && topk_key(e[q]) >= bound) {
+                        const float x = is_seen(i) ? e[q] - fabsf(e[q] * 1.0f) * 100000000.0f : e[q];
+                        const unsigned k = topk_key(x);
+                        if (k >= bound) {
+                            const int pos = atomicAdd(&s_ncand, 1);
+                            if (pos < TOPK_NCAND) { candk[pos] = k; candi[pos] = i; }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TOPK_RV4; ++j) cur[j] = nxt[j];
+            if ((c & 3) == 3 && c + 1 < nchunk) {
+                // every fourth chunk: does the list need tightening?  (uniform: read behind a barrier)
+                __syncthreads();
+                const int n = s_ncand;
+                if (n > TOPK_NCAND) { overflow = true; break; }
+                if (n > TOPK_NCAND / 2) {
+                    topk_radix_select([&](int i) { return candk[i]; }, n, K, hist, &s_prefix, &s_remaining);
+                    const unsigned T = s_prefix;
+                    unsigned kk[4];
+                    int ii[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = tid + 1024 * j;
+                        kk[j] = i < n ? candk[i] : 0u;
+                        ii[j] = i < n ? candi[i] : 0;
+                    }
+                    __syncthreads();
+                    if (tid == 0) s_ncand = 0;
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (tid + 1024 * j < n && kk[j] >= T) {
+                            const int pos = atomicAdd(&s_ncand, 1);
+                            candk[pos] = kk[j];
+                            candi[pos] = ii[j];
+                        }
+                    __syncthreads();
+                    bound = T;
+                    if (s_ncand > TOPK_NCAND / 2) { overflow = true; break; }     // (a flood of ties at the bound)
+                }
+            }
+        }
+        __syncthreads();
+        if (!overflow && s_ncand > TOPK_NCAND) overflow = true;
+        if (overflow) {          // uniform: start again on the legacy path
+            __syncthreads();
+            streamed = false;
+            mask_setup();
+            if (tid == 0) s_ncand = 0;
+            __syncthreads();
+        }
+    }
     unsigned keys[TOPK_RV4][4];
     if (in_regs) {
         unsigned m = 0u;
@@ -541,35 +681,37 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
             }
         }
         tk[tid] = m;
-    } else {
+    } else if (!streamed) {
         unsigned m = 0u;
         for (int i = tid; i < I; i += 1024) { const unsigned k = topk_key(val(i)); m = k > m ? k : m; }
         tk[tid] = m;
     }
-    __syncthreads();
-    topk_radix_select([&](int i) { return tk[i]; }, 1024, K, hist, &s_prefix, &s_remaining);
-    const unsigned bound = s_prefix;
-    if (in_regs) {
+    if (!streamed) {
+        __syncthreads();
+        topk_radix_select([&](int i) { return tk[i]; }, 1024, K, hist, &s_prefix, &s_remaining);
+        const unsigned bound = s_prefix;
+        if (in_regs) {
 #pragma unroll
-        for (int j = 0; j < TOPK_RV4; ++j)
+            for (int j = 0; j < TOPK_RV4; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int i = 4 * (tid + 1024 * j) + c;
-                if (i < I && keys[j][c] >= bound) {
+                for (int c = 0; c < 4; ++c) {
+                    const int i = 4 * (tid + 1024 * j) + c;
+                    if (i < I && keys[j][c] >= bound) {
+                        const int pos = atomicAdd(&s_ncand, 1);
+                        if (pos < TOPK_NCAND) { candk[pos] = keys[j][c]; candi[pos] = i; }
+                    }
+                }
+        } else {
+            for (int i = tid; i < I; i += 1024) {
+                const unsigned k = topk_key(val(i));
+                if (k >= bound) {
                     const int pos = atomicAdd(&s_ncand, 1);
-                    if (pos < TOPK_NCAND) { candk[pos] = keys[j][c]; candi[pos] = i; }
+                    if (pos < TOPK_NCAND) { candk[pos] = k; candi[pos] = i; }
                 }
             }
-    } else {
-        for (int i = tid; i < I; i += 1024) {
-            const unsigned k = topk_key(val(i));
-            if (k >= bound) {
-                const int pos = atomicAdd(&s_ncand, 1);
-                if (pos < TOPK_NCAND) { candk[pos] = k; candi[pos] = i; }
-            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     const int ncand = s_ncand;
     const bool filtered = ncand <= TOPK_NCAND;          // uniform; otherwise (heavy ties) select over all scores
     if (filtered) topk_radix_select([&](int i) { return candk[i]; }, ncand, K, hist, &s_prefix, &s_remaining);
@@ -847,13 +989,22 @@ extern "C" int svae_gather_rows(const float* in, const int* idx, float* out, int
 }
 
 // Reference interface replaced: seen-item mask + torch.sort(-scores)[:k] in evaluate() (nb:621-636).
+static void topk_launch(const float* scores, int ld, const int* seen, const int* seen_off, int n_users, int I, int K,
+                        int* out_idx, float* out_val, float* work, hipStream_t st) {
+    if (I > 4096 * TOPK_RV4)
+        hipLaunchKernelGGL(masked_topk_kernel<true>, dim3(n_users), dim3(1024), 0, st, scores, ld, seen, seen_off, I, K,
+                           out_idx, out_val, work);
+    else
+        hipLaunchKernelGGL(masked_topk_kernel<false>, dim3(n_users), dim3(1024), 0, st, scores, ld, seen, seen_off, I, K,
+                           out_idx, out_val, work);
+}
+
 // work is a scratch copy of the scores, [n_users][ld].
 extern "C" int svae_masked_topk(const float* scores, int ld, const int* seen, const int* seen_off, int n_users, int I,
                                 int K, int* out_idx, float* out_val, float* work, void* stream) {
     SV_CHECK_ARG(scores && seen && seen_off && out_idx && out_val && work, "svae_masked_topk: null pointer");
     SV_CHECK_ARG(n_users > 0 && I > 0 && ld >= I && K >= 1 && K <= I, "svae_masked_topk: bad shape");
-    hipLaunchKernelGGL(masked_topk_kernel, dim3(n_users), dim3(1024), 0, (hipStream_t)stream, scores, ld, seen,
-                       seen_off, I, K, out_idx, out_val, work);
+    topk_launch(scores, ld, seen, seen_off, n_users, I, K, out_idx, out_val, work, (hipStream_t)stream);
     SV_LAUNCH_CHECK();
     return 0;
 }
@@ -947,8 +1098,7 @@ extern "C" int svae_masked_topk_static(const float* scores, int ld, const int* s
     float* work = nullptr;
     const int rc = svae_scratch_setup(&work);
     if (rc != 0) return rc;
-    hipLaunchKernelGGL(masked_topk_kernel, dim3(n_users), dim3(1024), 0, (hipStream_t)stream, scores, ld, seen,
-                       seen_off, I, K, out_idx, out_val, work);
+    topk_launch(scores, ld, seen, seen_off, n_users, I, K, out_idx, out_val, work, (hipStream_t)stream);
     SV_LAUNCH_CHECK();
     return 0;
 }

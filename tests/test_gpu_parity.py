@@ -391,6 +391,26 @@ def test_masked_topk_equals_stable_descending_sort_on_edge_cases():
     small = torch.randn(3, 50, generator=g)
     run(small, [[], [1], [2, 3]], 50)
     run(torch.randn(2, 3000, generator=g), [[], []], 2000)             # K above the LDS sort: arg-max rounds
+    # ---- catalogues beyond 24 576 items: the STREAMED path (round 3: the row read once in register-resident chunks, the
+    # seen items in a hash set, the bound tightened by selecting over the candidate list)
+    for I in (24580, 30000, 131072 + 4, 200000):
+        big = torch.randn(3, I, generator=g)
+        top = torch.topk(big[1], 300).indices.tolist()                  # a user who has SEEN its 300 best items
+        run(big, [[0, I - 1, 12345], top, list(range(0, 2700, 3))], 100)
+    I = 100000
+    asc = torch.arange(I, dtype=torch.float32).repeat(2, 1) * 1e-3      # ascending rows: every chunk beats the bound of
+    run(asc, [[], [I - 1, I - 2, I - 50]], 100)                         # the chunks before it (the list is tightened)
+    quant = torch.randint(0, 50, (2, I), generator=g).float()           # 2 000 ties per value: a flood at the bound
+    run(quant, [[], [7, 8, 9]], 100)                                    # (-> starts again on the legacy path)
+    run(torch.full((2, 40000), -1.5), [[], [3]], 100)                   # constant rows
+    many = torch.randn(2, 60000, generator=g)
+    run(many, [list(range(0, 925)), list(range(0, 2000, 2))], 100)      # K + seen = 1025 and 1100 > 1024: legacy path
+    run(many, [list(range(0, 924)), [5]], 100)                          # K + seen = 1024: the streamed path's limit
+    run(torch.randn(2, 50000, generator=g), [[], [1]], 1)
+    run(torch.randn(2, 50000, generator=g), [[], [1]], 1000)
+    neg = -torch.rand(2, 70000, generator=g) - 1.0                      # all scores negative; zeros among the seen
+    neg[1, 11] = 0.0
+    run(neg, [[], [11, 12]], 100)
 
 
 def test_postfix_targets_beyond_256_per_row_vs_oracle():
