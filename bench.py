@@ -137,7 +137,10 @@ def main():
     for p_ in plans:
         eng.prepare(p_)
     if world > 1 or rehearse:
-        eng.grad_sync = GradSync(eng.grads, eng.layout.buckets(), force=rehearse)
+        # SVAE_DP_NATIVE=1: the collectives through the library's own RCCL wrappers, in order on the producing streams
+        # (dist.GradSync(native=True); opt-in: it has only run at world size 1)
+        eng.grad_sync = GradSync(eng.grads, eng.layout.buckets(), force=rehearse,
+                                 native=os.environ.get("SVAE_DP_NATIVE", "0") == "1")
         # large catalogues: the item-embedding gradient (one non-zero row per distinct input item of the batch) goes
         # over the wire as (row id, row) pairs when that is fewer bytes than the dense all-reduce of the table
         cap_rows = max(p_.R for p_ in plans)
@@ -474,6 +477,7 @@ def main():
                                    % (shape_name, shape_cfg, I, lmax, B),
                        "items": I, "batch_per_gpu": B, "mean_rows_per_step": rows, "mean_rows_bracketed_steps": rows_timed, "parallelism": "dp%d" % world, "embedding_gradient_exchange": ("rows" if (eng.grad_sync is not None and eng.grad_sync.sparse is not None) else "dense"),
                        "caller_stream": ("high priority (SVAEEngine.training_stream, as train_batched)" if os.environ.get("SVAE_TRAIN_HIPRIO", "1") == "1" else "default"),
+                       "collectives": ("library RCCL wrappers on the producing streams" if (eng.grad_sync is not None and eng.grad_sync.native) else ("torch.distributed" if eng.grad_sync is not None else None)),
                        "decoder_linear2_exchange": ("reduce-scatter + sharded optimizer + all-gather" if (eng.grad_sync is not None and eng.grad_sync.sharded is not None) else "all-reduce"),
                        "final_loss": loss, "side_stream": eng.side_stream_info},
             "kernel_ms": kt, "kernel_timing": "HIP events on the launch streams over a replay of the first %d timed steps "

@@ -338,6 +338,14 @@ int svae_heldout_ranks(const int* topk_idx, int n_users, int K, const long long*
                        const int* held, const long long* held_off, long long n_total_users, int* rank_out,
                        void* stream);
 
+/* No counterpart in the reference (single process).  The rebuild behind the sparse exchange of the item-embedding
+ * gradient in data parallel runs: all_ids [world][cap] (int64, -1 = padding) and all_vals [world][cap][width] are the
+ * all-gathered (row id, row) pairs; the rank's own rows (own_ids[0..n_own)) of table [rows][width] are zeroed, then the
+ * ranks' rows are added in rank order (one launch per rank: the same additions in the same order on every rank).
+ * ids are distinct within a rank's list; width % 4 == 0. */
+int svae_sparse_rows_rebuild(float* table, long long rows, int width, const long long* all_ids, const float* all_vals,
+                             int world, int cap, const long long* own_ids, int n_own, void* stream);
+
 /* No counterpart in the reference.  svae_masked_topk for callers that CANNOT ALLOCATE the `work` buffer: code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernel and results; the scratch is
  * a static device array inside the library (32 MiB per GPU, held until the process ends): n_users * ld <= 8 Mi

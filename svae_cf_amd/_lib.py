@@ -48,6 +48,7 @@ SIGNATURES = {
     "svae_gather_rows": [_P, _P, _P, _I, _I, _I, _I, _P],
     "svae_masked_topk": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "svae_masked_topk_static": [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P],
+    "svae_sparse_rows_rebuild": [_P, _LL, _I, _P, _P, _I, _I, _P, _I, _P],
     "svae_heldout_ranks": [_P, _I, _I, _P, _P, _P, _P, _LL, _P, _P],
     "svae_philox_normal": [_P, _P, _I, _ULL, _U, _P],
     "svae_proj_prep_rows": [_P, _I, _I, _P, _P, _P, _P],

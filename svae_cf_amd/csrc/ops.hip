@@ -1049,6 +1049,55 @@ extern "C" int svae_heldout_ranks(const int* topk_idx, int n_users, int K, const
     return 0;
 }
 
+// ---- sparse exchange of the embedding gradient: the rebuild behind the all-gather -------------------------------
+// No counterpart in the reference (single process).  Data parallel runs with large catalogues exchange the item-embedding
+// gradient as (row id, row) pairs (dist.GradSync.enable_sparse_rows): after the all-gather every rank holds world lists
+// of cap pairs (id -1 = padding) and rebuilds the SUMMED rows in its own gradient table: its own rows zeroed first, then
+// rank 0's rows added, then rank 1's, ... -- one launch per rank on one stream, so the additions happen in the same
+// order on every rank (replicas stay bit-identical) and, ids being distinct within a rank's list, without atomics.
+// One wave per pair; rows of `width` floats (a multiple of 4).  Replaces torch's index_fill_ / index_add_ on the product
+// path (round 2's review), pad entries are skipped instead of being multiplied by zero.
+__global__ __launch_bounds__(256) void sparse_rows_zero_kernel(float* __restrict__ table, int width,
+                                                              const long long* __restrict__ ids, int n, long long rows) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const long long id = ids[i];
+    if (id < 0 || id >= rows) return;
+    float4* dst = reinterpret_cast<float4*>(table + (size_t)id * width);
+    for (int c = lane; c < width / 4; c += 64) dst[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ __launch_bounds__(256) void sparse_rows_add_kernel(float* __restrict__ table, int width,
+                                                             const long long* __restrict__ ids,
+                                                             const float* __restrict__ vals, int n, long long rows) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const long long id = ids[i];
+    if (id < 0 || id >= rows) return;
+    float4* dst = reinterpret_cast<float4*>(table + (size_t)id * width);
+    const float4* src = reinterpret_cast<const float4*>(vals + (size_t)i * width);
+    for (int c = lane; c < width / 4; c += 64) {
+        float4 a = dst[c];
+        const float4 b = src[c];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[c] = a;
+    }
+}
+extern "C" int svae_sparse_rows_rebuild(float* table, long long rows, int width, const long long* all_ids,
+                                        const float* all_vals, int world, int cap, const long long* own_ids, int n_own,
+                                        void* stream) {
+    SV_CHECK_ARG(table && all_ids && all_vals && (own_ids || n_own == 0), "svae_sparse_rows_rebuild: null pointer");
+    SV_CHECK_ARG(rows > 0 && width > 0 && (width % 4) == 0 && world >= 1 && cap >= 1 && n_own >= 0 && n_own <= cap,
+                 "svae_sparse_rows_rebuild: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (n_own > 0)
+        hipLaunchKernelGGL(sparse_rows_zero_kernel, dim3((n_own + 3) / 4), dim3(256), 0, st, table, width, own_ids, n_own, rows);
+    for (int r = 0; r < world; ++r)
+        hipLaunchKernelGGL(sparse_rows_add_kernel, dim3((cap + 3) / 4), dim3(256), 0, st, table, width,
+                           all_ids + (size_t)r * cap, all_vals + (size_t)r * cap * width, cap, rows);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- the same top-k for callers that cannot allocate (no counterpart in the reference) -----------------------
 // svae_masked_topk takes its scratch copy of the scores (`work`) from the caller, who has to allocate it.  Code under
 // HIP graph capture, a tight serving loop or a harness that forbids hipMalloc cannot: svae_masked_topk_static runs the

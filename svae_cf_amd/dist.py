@@ -22,13 +22,24 @@ class GradSync:
     build it never completed (both ranks blocked in Work.wait(); seen with tests/test_gpu_dp.py).
     ``force`` keeps the collectives at world size 1 (rehearsal of the RCCL call path on one GPU)."""
 
-    def __init__(self, flat_grads, buckets, group=None, force=False):
+    def __init__(self, flat_grads, buckets, group=None, force=False, native=False):
         self.flat = flat_grads
         self.buckets = list(buckets)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = dist.is_initialized() and (self.world > 1 or force)
         self.device_collectives = self.active and dist.get_backend(group) == "nccl"
+        # native (opt-in, round 3): the collectives are issued through the library's own RCCL wrappers
+        # (svae_allreduce_sum_f32 / svae_reduce_scatter_sum_f32 / svae_allgather_f32, csrc/comm.hip) IN ORDER on the
+        # stream that is current when a bucket is announced -- the stream that produced it -- with one communicator per
+        # such stream, instead of torch.distributed's collectives on its own stream with an event hop on either side
+        # (43 us per step at world size 1, profiles/r02n_dp_rehearsal_rccl_world1.json.log).  `wait` then has nothing to
+        # do: the consumers follow on the same stream.  torch.distributed is only used to hand rank 0's communicator id
+        # to the other ranks.  NOT the default: it has only ever run at world size 1 (one GPU per box here).
+        self.native = bool(native) and flat_grads.is_cuda and (self.device_collectives or (force and self.world == 1))
+        if self.native:
+            self.active = True
+        self._comms = {}
         self.pending = []
         self.sparse = None        # (bucket, rows, width, capacity, buffers): see enable_sparse_rows
         self.sharded = None       # (bucket, shard length, rank): see enable_sharded
@@ -61,6 +72,11 @@ class GradSync:
             return None
         s, e = self.buckets[self.sharded["bucket"]]
         a, b = self.shard_range()
+        if self.native:
+            from . import _lib
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.call("svae_allgather_f32", self._comm(st), flat_params[s:e].data_ptr(), b - a, self.rank, st)
+            return None
         if self.device_collectives or not flat_params.is_cuda:
             # in place: a rank's shard is its part of the gathered buffer
             src = flat_params[a:b] if self.device_collectives else flat_params[a:b].clone()
@@ -91,6 +107,32 @@ class GradSync:
                            all_vals=torch.zeros(self.world * capacity, width, dtype=self.flat.dtype, device=dev),
                            spread=torch.arange(capacity, dtype=torch.int64, device=dev) % n_rows)
 
+    def _comm(self, stream_ptr):
+        """The communicator of the stream `stream_ptr` (native mode): created on first use -- collectively, every rank
+        reaches this point in the same order -- from a 128-byte id that rank 0 makes and torch.distributed hands round."""
+        c = self._comms.get(stream_ptr)
+        if c is None:
+            import ctypes
+            from . import _lib
+            ident = ctypes.create_string_buffer(128)
+            if self.rank == 0:
+                _lib.call("svae_rccl_unique_id", ident)
+            if self.world > 1:
+                box = [bytes(ident.raw)]
+                dist.broadcast_object_list(box, src=0, group=self.group)
+                ident = ctypes.create_string_buffer(box[0], 128)
+            comm = ctypes.c_void_p()
+            _lib.call("svae_rccl_comm_create", ctypes.byref(comm), self.world, self.rank, ident)
+            c = self._comms[stream_ptr] = comm.value
+        return c
+
+    def close(self):
+        """Destroy the native communicators (call with the device idle)."""
+        from . import _lib
+        for c in self._comms.values():
+            _lib.call("svae_rccl_comm_destroy", c)
+        self._comms = {}
+
     @staticmethod
     def sparse_rows_pay(n_rows, capacity, world):
         """True when the (id, row) exchange moves fewer bytes than the dense all-reduce of the table's gradient
@@ -108,6 +150,19 @@ class GradSync:
         s, _ = self.buckets[sp["bucket"]]
         table = self.flat[s:s + sp["rows"] * sp["width"]].view(sp["rows"], sp["width"])
         own = ids[:n].to(torch.int64)
+        if self.native:
+            # in place: this rank's pairs are its part of the gathered buffers (ids as pairs of 4-byte words)
+            from . import _lib
+            cap, r, st = sp["cap"], self.rank, torch.cuda.current_stream().cuda_stream
+            mine_i, mine_v = sp["all_ids"][r * cap:(r + 1) * cap], sp["all_vals"][r * cap:(r + 1) * cap]
+            mine_i.fill_(-1)
+            mine_i[:n] = own
+            mine_v[:n] = table.index_select(0, own)
+            comm = self._comm(st)
+            _lib.call("svae_allgather_f32", comm, sp["all_ids"].data_ptr(), 2 * cap, r, st)
+            _lib.call("svae_allgather_f32", comm, sp["all_vals"].data_ptr(), cap * sp["width"], r, st)
+            self._sparse_rebuild(table, own)
+            return
         sp["ids"].fill_(-1)
         sp["ids"][:n] = own
         sp["vals"][:n] = table.index_select(0, own)
@@ -127,6 +182,14 @@ class GradSync:
 
     def _sparse_rebuild(self, table, own):
         sp = self.sparse
+        if table.is_cuda:
+            # one zeroing launch and one adding launch per rank, in rank order (svae_sparse_rows_rebuild)
+            from . import _lib
+            _lib.call("svae_sparse_rows_rebuild", table.data_ptr(), sp["rows"], sp["width"], sp["all_ids"].data_ptr(),
+                      sp["all_vals"].data_ptr(), self.world, sp["cap"], own.data_ptr(), int(own.numel()),
+                      torch.cuda.current_stream().cuda_stream)
+            own.record_stream(torch.cuda.current_stream())
+            return
         table.index_fill_(0, own, 0.0)
         cap = sp["cap"]
         for r in range(self.world):                       # fixed order: the replicas stay bit-identical
@@ -144,6 +207,15 @@ class GradSync:
         if not self.active:
             return
         s, e = self.buckets[i]
+        if self.native:
+            from . import _lib
+            st = torch.cuda.current_stream().cuda_stream
+            if self.sharded is not None and self.sharded["bucket"] == i:
+                _lib.call("svae_reduce_scatter_sum_f32", self._comm(st), self.flat[s:e].data_ptr(), self.sharded["shard"],
+                          self.rank, st)
+            else:
+                _lib.call("svae_allreduce_sum_f32", self._comm(st), self.flat[s:e].data_ptr(), e - s, st)
+            return
         if self.sharded is not None and self.sharded["bucket"] == i and self.device_collectives:
             a, b = self.shard_range()          # in place: the rank's shard of the sum lands in its part of the bucket
             self.pending.append((i, dist.reduce_scatter_tensor(self.flat[a:b], self.flat[s:e], op=dist.ReduceOp.SUM,

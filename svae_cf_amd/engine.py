@@ -510,9 +510,18 @@ class SVAEEngine:
         # decoder side
         # With a two-range forward (below) only the rows of the first range's timesteps are needed by the recurrence
         # that heads the step: their gather and input gates here, the others' on the side stream beside it (+1.2 %).
-        gi_split = (plan.split_r if (self.fused and self.rowgemm and self.gi_split and self.overlap and self.time_split
-                                     and want_loss and want_grad and self.gru_prec in (PREC_BF16, PREC_SPLIT) and plan.split_t > 0)
-                    else 0)
+        # The first recurrence reads the input gates of EVERY row of its timesteps, rows < row_off[t1] -- which is up to 63
+        # rows more than plan.split_r (that cut is rounded DOWN to 64 rows for the decoder side): the head's share ends
+        # at row_off[t1] rounded UP.  (Round 2 cut both at split_r: the rows in between were gathered and multiplied on
+        # the side stream, usually AFTER the first recurrence had read them -- it then saw the input gates of the batch
+        # before.  Invisible to every test that repeats one plan; found in round 3 with
+        # tests/test_gpu_fullsize.py::test_a_step_does_not_depend_on_the_batch_before_it.)
+        gi_split = 0
+        if (self.fused and self.rowgemm and self.gi_split and self.overlap and self.time_split and want_loss and want_grad
+                and self.gru_prec in (PREC_BF16, PREC_SPLIT) and plan.split_t > 0):
+            gi_split = (int(plan._row_off_host[plan.split_t]) + 63) // 64 * 64
+            if gi_split >= R:
+                gi_split = 0
         head_fused = self.fused and self.rowgemm and self.prec == PREC_BF16 and self.head_fused
         # (bf16 rows need the bf16 gradient array on the other side: the weight-gradient kernel's bf16-X form reads both)
         # (the fused loss paths only: training, whose backward then has the bf16 gradient array, and scoring, which

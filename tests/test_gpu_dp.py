@@ -209,3 +209,75 @@ def test_c_abi_rccl_wrappers_world_size_one():
             _lib.call("svae_allreduce_sum_f32", comm, g.data_ptr(), 0, st)
     finally:
         _lib.call("svae_rccl_comm_destroy", comm)
+
+
+def test_sparse_rows_rebuild_kernel_equals_the_rank_ordered_sum():
+    """svae_sparse_rows_rebuild (the rebuild behind the sparse exchange of the embedding gradient): own rows zeroed, then
+    every rank's (id, row) pairs added in rank order, pad entries (-1) skipped whatever their values hold (Inf / NaN
+    left over from an earlier step must not leak: round 2's advisor finding).  Bit-identical to the same additions in
+    the same order on the host."""
+    sys.path.insert(0, ROOT)
+    from svae_cf_amd import _lib
+    rs = np.random.RandomState(4)
+    rows, width, world, cap = 5000, 256, 3, 700
+    table = rs.standard_normal((rows, width)).astype(np.float32)
+    all_ids = np.full((world, cap), -1, dtype=np.int64)
+    all_vals = rs.standard_normal((world, cap, width)).astype(np.float32)
+    counts = [650, 0, 700]
+    for r, n in enumerate(counts):
+        all_ids[r, :n] = rs.permutation(rows)[:n]
+        all_vals[r, n:] = np.float32("nan") if r == 0 else np.float32("inf")       # stale contents behind the count
+    own = all_ids[0, :counts[0]].copy()
+    ref = table.copy()
+    ref[own] = 0.0
+    for r in range(world):
+        for i in range(counts[r]):
+            ref[all_ids[r, i]] = ref[all_ids[r, i]] + all_vals[r, i]
+    t = torch.from_numpy(table).cuda()
+    ids_d, vals_d, own_d = torch.from_numpy(all_ids).cuda(), torch.from_numpy(all_vals).cuda(), torch.from_numpy(own).cuda()
+    _lib.call("svae_sparse_rows_rebuild", t.data_ptr(), rows, width, ids_d.data_ptr(), vals_d.data_ptr(), world, cap,
+              own_d.data_ptr(), len(own), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.from_numpy(ref))
+
+
+@pytest.mark.parametrize("sparse,sharded", [(False, False), (True, True)])
+def test_native_collectives_at_world_size_one_reproduce_the_plain_step(sparse, sharded):
+    """dist.GradSync(native=True): the buckets' collectives through the library's own RCCL wrappers, issued in order on
+    the streams that produce them (one communicator per stream), at world size 1 -- all there is on a one-GPU box.  The
+    step with them (dense all-reduce, or the embedding gradient as (id, row) pairs + the decoder.linear2 bucket as
+    reduce-scatter / sharded optimizer / all-gather) must leave the parameters of the plain single-process step, bit
+    for bit, over three steps."""
+    sys.path.insert(0, ROOT)
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    from svae_cf_amd.dist import GradSync
+    from svae_cf_amd.layout import E
+    I, B = 20000, 128
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(B, I, mu, sigma, lmax, seed=77)
+    plan = S.build_plan(users, 4, user_keys=np.arange(B), device="cuda", total_items=I)
+    got = []
+    for native in (False, True):
+        eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+        g = torch.Generator().manual_seed(3)
+        eng.load_state_dict({n: (torch.randn(s_, generator=g) * (0.07 if n != "item_embed.weight" else 1.0))
+                             for n, s_ in eng.layout.ref_shapes.items()})
+        eng.prepare(plan)
+        gs = None
+        if native:
+            gs = eng.grad_sync = GradSync(eng.grads, eng.layout.buckets(), force=True, native=True)
+            assert gs.native and gs.active and gs.world == 1
+            if sparse:
+                gs.enable_sparse_rows(2, I, E, capacity=plan.R)
+            if sharded:
+                gs.enable_sharded(0)
+        for s_ in range(3):
+            eng.train_step(plan, 0.05, seed=9, step=s_)
+        torch.cuda.synchronize()
+        got.append((eng.params.clone(), eng.loss_out.clone()))
+        if gs is not None:
+            assert len(gs._comms) >= 1
+            gs.close()
+    assert torch.equal(got[0][1], got[1][1])
+    assert torch.equal(got[0][0], got[1][0])

@@ -333,3 +333,129 @@ def test_caller_supplied_noise_on_a_time_split_plan():
         assert torch.equal(eng.params, got[side]["params"]), "a refused call must not have run anything"
     for k in got[False]:
         assert torch.equal(got[False][k], got[True][k]), k
+
+
+@pytest.mark.parametrize("prec_name", ["bf16", "split"])
+def test_a_step_does_not_depend_on_the_batch_before_it(prec_name):
+    """Every kernel of a step must read what THIS step wrote: the workspace is reused from step to step, and a read that
+    runs ahead of its producer (streams!) sees the batch before -- silently, in every test that repeats one plan.  Here
+    an engine runs batch A and then batch B (other users, other lengths), a second engine of the same parameters runs
+    batch B with its workspace poisoned (NaN in every fp32 array, 0x7fff patterns in the bf16 ones): loss, every
+    gradient and every saved activation of batch B must be bit-identical -- and finite.  Forward + backward without an
+    optimizer step in between, so that the two engines hold the same parameters; time-split plans, both precisions
+    whose recurrence runs in two ranges; the second engine's side streams are held back for 3 ms first, so that a race
+    between the streams is lost for certain.  (Round 3: this catches the first recurrence reading input gates that the
+    side stream had not written yet -- rows between the decoder-side cut and row_off[t1].)"""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    I, B = 20000, 128
+    prec = S.PREC_BF16 if prec_name == "bf16" else S.PREC_SPLIT
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(4 * B, I, mu, sigma, lmax, seed=77)
+    plans = []
+    for c in range(4):          # (unsorted chunks: mixed lengths, so that the plans have a time split)
+        cand = np.arange(c * B, (c + 1) * B)
+        p = S.build_plan([users[i] for i in cand], 4, user_keys=cand, device="cuda", total_items=I)
+        if p.split_t > 0 and int(p._row_off_host[p.split_t]) % 64 != 0:
+            plans.append(p)
+    assert len(plans) >= 2, "need two time-split plans whose cut is not a multiple of 64 rows"
+    pa, pb = plans[0], plans[1]
+    assert pa.R != pb.R
+
+    def engine():
+        eng = S.SVAEEngine(I, device="cuda", prec=prec)
+        _init(eng, 21)
+        eng.reserve(max(pa.R, pb.R))
+        eng.prepare(pa)
+        eng.prepare(pb)
+        return eng
+
+    def run(eng, plan, hold_side_us=0):
+        if hold_side_us:
+            # race detector: the engine's side streams are held back, so that whatever the caller's stream reads from
+            # them without waiting for them is still the poison (a lost race, on demand)
+            from svae_cf_amd import _lib
+            cur = torch.cuda.current_stream()
+            sides = [eng._side_stream(which, cur=cur) for which in (0, 1)]     # (choosing one synchronises: first)
+            for sd in sides:
+                _lib.call("svae_spin", hold_side_us, sd.cuda_stream)
+        loss = eng.forward(plan, 0.05, seed=9, step=4).clone()
+        eng.backward()
+        torch.cuda.synchronize()
+        keep = {k: v[:plan.R * (v.numel() // eng.cap)].clone() for k, v in eng.ws.items()
+                if k in ("gi", "hs", "gates4", "enc", "tmp", "z", "d1", "dd1", "dhs", "demb", "nll_row", "lse", "kl_row")}
+        return loss, eng.grads.clone(), keep
+
+    e1 = engine()
+    # (on the engine's training stream, as train_batched runs its steps -- not the legacy default stream)
+    with torch.cuda.stream(e1.training_stream()):
+        run(e1, pa)
+        got1 = run(e1, pb)
+        e2 = engine()
+        run(e2, pa)                                    # (a first, plain step: its side streams exist and are warm)
+        for k, v in e2.ws.items():
+            if v is None or v.numel() == 0:
+                continue
+            if v.dtype == torch.float32:
+                v.fill_(float("nan"))
+            elif k in ("dg4b", "emb16"):
+                v.view(torch.int16).fill_(0x7fc0)      # bf16 NaN
+        torch.cuda.synchronize()
+        got2 = run(e2, pb, hold_side_us=3000)
+    assert torch.isfinite(got2[0]).all() and torch.isfinite(got2[1]).all()
+    assert torch.equal(got1[0], got2[0]), (got1[0], got2[0])
+    for k in got1[2]:
+        assert torch.equal(got1[2][k], got2[2][k]), k
+    assert torch.equal(got1[1], got2[1])
+
+
+def test_a_training_step_does_not_depend_on_the_batch_before_it():
+    """The same detector over the whole `train_step` (optimizer and the floated decoder.linear2 work included): engine 1
+    trains on batch A then batch B; engine 2 trains on A, then its workspace is poisoned, its side streams are held back
+    for 3 ms, and it trains on B: the parameters and optimizer moments after B must be bit-identical and finite."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth, _lib
+    I, B = 20000, 128
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(4 * B, I, mu, sigma, lmax, seed=77)
+    plans = []
+    for c in range(4):
+        cand = np.arange(c * B, (c + 1) * B)
+        p = S.build_plan([users[i] for i in cand], 4, user_keys=cand, device="cuda", total_items=I)
+        if p.split_t > 0:
+            plans.append(p)
+    assert len(plans) >= 2
+    pa, pb = plans[0], plans[1]
+    out = []
+    for poisoned in (False, True):
+        eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+        _init(eng, 21)
+        eng.reserve(max(pa.R, pb.R))
+        eng.prepare(pa)
+        eng.prepare(pb)
+        with torch.cuda.stream(eng.training_stream()):
+            eng.train_step(pa, 0.05, seed=9, step=0)
+            if poisoned:
+                eng._settle()
+                torch.cuda.synchronize()
+                for k, v in eng.ws.items():
+                    if v is None or v.numel() == 0:
+                        continue
+                    if v.dtype == torch.float32:
+                        v.fill_(float("nan"))
+                    elif k in ("dg4b", "emb16"):
+                        v.view(torch.int16).fill_(0x7fc0)
+                for t in (eng.slabs, eng.slabs_side, eng.slabs_hh):
+                    t.fill_(float("nan"))
+                torch.cuda.synchronize()
+                cur = torch.cuda.current_stream()
+                sides = [eng._side_stream(which, cur=cur) for which in (0, 1)]
+                for sd in sides:
+                    _lib.call("svae_spin", 3000, sd.cuda_stream)
+            eng.train_step(pb, 0.05, seed=9, step=1)
+            eng._settle()
+        torch.cuda.synchronize()
+        out.append((eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), eng.loss_out.clone()))
+    for a, b in zip(*out):
+        assert torch.isfinite(b).all()
+        assert torch.equal(a, b)
