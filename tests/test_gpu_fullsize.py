@@ -459,3 +459,39 @@ def test_a_training_step_does_not_depend_on_the_batch_before_it():
     for a, b in zip(*out):
         assert torch.isfinite(b).all()
         assert torch.equal(a, b)
+
+
+def test_scoring_does_not_depend_on_the_batch_before_it():
+    """The detector over `score` (evaluate()'s per-batch work): batch A then batch B against batch B on a poisoned
+    workspace with the side streams held back -- loss, top-100 ids and values bit-identical."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth, _lib
+    I, B = 20000, 128
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(2 * B, I, mu, sigma, lmax, seed=78)
+    pa, pb = (S.build_plan(users[c * B:(c + 1) * B], 4, user_keys=np.arange(c * B, (c + 1) * B), device="cuda",
+                           total_items=I) for c in range(2))
+    out = []
+    for poisoned in (False, True):
+        eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+        _init(eng, 21)
+        eng.reserve(max(pa.R, pb.R))
+        eng.prepare(pa, scoring=True)
+        eng.prepare(pb, scoring=True)
+        eng.score(pa, 100, seed=3, step=0)
+        torch.cuda.synchronize()
+        if poisoned:
+            for k, v in eng.ws.items():
+                if v is not None and v.numel() and v.dtype == torch.float32:
+                    v.fill_(float("nan"))
+            torch.cuda.synchronize()
+            cur = torch.cuda.current_stream()
+            sides = [eng._side_stream(which, cur=cur) for which in (0, 1)]
+            for sd in sides:
+                _lib.call("svae_spin", 3000, sd.cuda_stream)
+        loss, idx, val, _ = eng.score(pb, 100, seed=3, step=1)
+        torch.cuda.synchronize()
+        out.append((loss.clone(), idx.clone(), val.clone()))
+    for a, b in zip(*out):
+        assert torch.isfinite(b.float()).all()
+        assert torch.equal(a, b)
