@@ -393,6 +393,11 @@ int svae_zero(void* p, long long nbytes, void* stream);
 /* One workgroup busy for usec microseconds: lets the host test whether two streams run concurrently (streams
  * that share a hardware queue do not).  No counterpart in the reference (single stream there). */
 int svae_spin(int usec, void* stream);
+/* nwg one-wave workgroups, each busy for usec microseconds and holding lds_bytes (<= 65536) of LDS: a launch whose
+ * DISPATCH lasts many rounds while most of the chip stays free.  Lets the host test whether a second stream's
+ * launches are held up behind it (queues that share a dispatcher pipe; engine.py, _pick_concurrent_stream).  No
+ * counterpart in the reference. */
+int svae_spin_grid(int usec, int nwg, int lds_bytes, void* stream);
 
 #ifdef __cplusplus
 }

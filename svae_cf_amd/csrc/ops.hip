@@ -1181,6 +1181,26 @@ extern "C" int svae_spin(int usec, void* stream) {
     return 0;
 }
 
+// A grid of `nwg` one-wave workgroups, each busy for `usec` microseconds and holding `lds_bytes` of LDS (so that only a
+// few fit a CU: the launch keeps its queue's dispatcher busy for many rounds while leaving most of the chip free).
+__global__ void spin_grid_kernel(unsigned long long ticks) {
+    extern __shared__ unsigned char spin_lds[];
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 20); ++i) {
+        if (wall_clock64() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (ticks == ~0ull) spin_lds[threadIdx.x] = 1;      // (keeps the allocation)
+}
+extern "C" int svae_spin_grid(int usec, int nwg, int lds_bytes, void* stream) {
+    SV_CHECK_ARG(usec > 0 && usec <= 10000 && nwg > 0 && nwg <= (1 << 20) && lds_bytes >= 0 && lds_bytes <= 65536,
+                 "svae_spin_grid: arguments out of range");
+    hipLaunchKernelGGL(spin_grid_kernel, dim3(nwg), dim3(64), (size_t)lds_bytes, (hipStream_t)stream,
+                       (unsigned long long)usec * 100ull);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
 // Zero fill (replaces the zero_grad pair nb:1197-1198 for the one gradient that is accumulated into, the embedding table's).
 extern "C" int svae_zero(void* p, long long nbytes, void* stream) {
     SV_CHECK_ARG(p && nbytes > 0, "svae_zero: bad arguments");

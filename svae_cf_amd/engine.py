@@ -185,7 +185,11 @@ class SVAEEngine:
         # workgroups of the weight-gradient sweep: it runs beside the BPTT (64 CUs) and the weight-gradient GEMMs, and
         # what it leaves them decides the step (one box, ms per step, two rounds: 144 -> 0.863 / 0.864, 158 -> 0.851 /
         # 0.855, 170 -> 0.922 / 0.921, 192 -> 0.932 / 0.930; balanced 2-way split = 158 workgroups: 0.859 / 0.858)
+        # Larger catalogues take more (_dw_workgroups: 192 above 51 200 items, the CU count less 32 above 100 000;
+        # 1M items: 158 -> 14.70, 224 -> 13.36 ms per step).  ML-1M shape: 96 .. 158 within 0.3 %.
         self.dw_wgs = int(_opt("SVAE_DW_WGS", "158"))
+        self.range1_cus = int(_opt("SVAE_RANGE1_CUS", "0"))           # tuning: workgroups of the first range's forward sweep
+        self.dw_wgs_exact = _opt("SVAE_DW_WGS_EXACT", "0") == "1"     # tuning: dw_wgs as given, whatever the shape
         self.head_fused = _opt("SVAE_HEAD_FUSED", "1") == "1"
         # bf16 mode: the gathered embedding rows are kept as bf16 (their two consumers -- the input-gate GEMM and the
         # input-weight gradient -- round them to bf16 anyway: bit-identical) -- half the bytes written by the gather,
@@ -377,7 +381,18 @@ class SVAEEngine:
         return self._sides[which]
 
     def _pick_concurrent_stream(self, others, tries=8, usec=200):
-        """A stream that runs concurrently with every stream of `others` (others[0] = the caller's)."""
+        """A stream that runs concurrently with every stream of `others` (others[0] = the caller's) AND whose launches
+        are not held up behind theirs.  Two tests, because HIP gives a process 4 hardware queues and maps further
+        streams onto the same ones (tools/probe/queue_pipe_probe.py: null, s0, s1, s2 get a queue each; s3 shares
+        s2's, s4 s1's, s5 s0's, and a high-priority stream created after them the null stream's):
+         1. one-workgroup spin kernels on all the streams at once finish in the time of one (streams on DIFFERENT
+            queues, or on one queue without a barrier between their packets -- this test alone passes both);
+         2. a launch whose DISPATCH is long (8192 one-wave workgroups, two per CU) on one stream does not delay a
+            one-workgroup kernel on the other: packets of one queue are dispatched in order, so streams that share a
+            queue fail this.  It is what hurts the step: a finish kernel or the optimizer (3-5 000 workgroups) on the
+            floating stream held every launch of the caller's stream for its whole length -- 1.17 instead of 0.85 ms
+            per step for a loop on the default stream after an epoch on the training stream (round 3,
+            tools/probe/default_stream_probe.py train_first)."""
         cur = others[0]
         prio = self.side_prio[min(len(others) - 1, len(self.side_prio) - 1)]
         dev = self._dev_index()
@@ -401,10 +416,29 @@ class SVAEEngine:
             e1.record(cur)
             e1.synchronize()
             return e0.elapsed_time(e1) * 1e3
+
+        def held_behind(sa, sb):
+            """Is a small kernel on sb held until a long dispatch on sa is through?  (fraction of that dispatch's length
+            after which the small kernel finished: ~0.15 independent, ~1 held)"""
+            worst = 0.0
+            for _ in range(2):
+                torch.cuda.synchronize(self.device)
+                e0, eb, ea = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record(sa)
+                sb.wait_event(e0)
+                _lib.call("svae_spin_grid", 10, 8192, 65536, sa.cuda_stream)
+                _lib.call("svae_spin", 10, sb.cuda_stream)
+                eb.record(sb)
+                ea.record(sa)
+                ea.synchronize()
+                eb.synchronize()
+                frac = e0.elapsed_time(eb) / max(e0.elapsed_time(ea), 1e-3)
+                worst = frac if _ == 0 else min(worst, frac)     # the better of two: a one-off delay is not sharing
+            return worst
         with _POOL_LOCK:
             pool = _STREAM_POOL.setdefault((dev, prio), [])
         taken = set(o.cuda_stream for o in others)
-        cands, times, choice = [], [], None
+        cands, times, infos, choice = [], [], [], None
         for i in range(tries):
             with _POOL_LOCK:
                 if i >= len(pool):
@@ -414,14 +448,20 @@ class SVAEEngine:
                 continue
             spin_all(c)                       # first use of a stream creates its queue: not timed
             t = min(spin_all(c), spin_all(c))
+            conc = t < 1.5 * usec
+            held = max(max(held_behind(o, c), held_behind(c, o)) for o in others) if conc else 1.0
+            info = dict(tried=len(times) + 1, all_us=t, concurrent=conc, held_frac=round(held, 3),
+                        dispatch_independent=held < 0.6)
             cands.append(c)
-            times.append(t)
-            if t < 1.5 * usec:
-                choice = (c, dict(tried=len(times), all_us=t, concurrent=True))
+            times.append((not conc, held >= 0.6, t))
+            infos.append(info)
+            if conc and held < 0.6:
+                choice = (c, info)
                 break
         if choice is None:
+            # nothing passed both tests (more streams in use than the process has queues): the best of what there is
             best = min(range(len(times)), key=lambda i: times[i])
-            choice = (cands[best], dict(tried=len(times), all_us=times[best], concurrent=False))
+            choice = (cands[best], infos[best])
         with _POOL_LOCK:
             _SIDE_CHOICE[ckey] = choice
         self.side_stream_info.append(choice[1])
@@ -643,7 +683,7 @@ class SVAEEngine:
                 self._float_plan = None       # (kept alive until here: the floated kernels read its tables)
             if t1 > 0:
                 self._last_fused = True
-                self._decoder_rows(plan, 0, r1, self._ncu - (plan.B + 3) // 4)
+                self._decoder_rows(plan, 0, r1, self._range1_cus(plan))
                 _lib.stream_wait(cur, second_done)
                 self._decoder_rows(plan, r1, R, self._ncu, mlp=not self.mlp2_side)
                 self._fused_grad = True
@@ -782,7 +822,7 @@ class SVAEEngine:
         ncu = self._ncu if ncu is None else max(8, int(ncu))
         flat = (self.flat_sched and not self.split) if flat is None else bool(flat)
         if flat:
-            nwg_want = min(ncu, self.dw_wgs) if side == "items" else ncu
+            nwg_want = self._dw_workgroups(plan.R, ncu) if side == "items" else ncu
             key = (side, self.I, nwg_want, nx, "flat", self.flat_boundary)
             shape = (("rows-flat", ((plan.R if nx is None else nx) + 255) // 256, nwg_want, self.flat_boundary) if side == "rows"
                      else ("items-flat", (plan.R + 63) // 64, nwg_want, self.flat_boundary))
@@ -830,6 +870,35 @@ class SVAEEngine:
         t, n, q, rem = cache[key]
         return (t.data_ptr(), n, q, rem)
 
+    def _dw_workgroups(self, R, ncu):
+        """Workgroups of the flat weight-gradient sweep (see `dw_wgs`): by catalogue size, from the measured optima --
+        the sweep grows with rows x items and what runs beside it only with rows, so its share of the chip grows with
+        the catalogue, but not smoothly (the step time has cliffs where the caller's chain stops finding CUs).  ms per
+        step at B = 256 (tools/ab_multi.sh with SVAE_DW_WGS_EXACT=1, one box per row):
+          20 000 items   152: 0.863   158: 0.857   160: 0.856   170: 0.922   192: 0.932
+          40 000         158: 1.237   168: 1.283   192: 1.280   200: 1.343
+          65 536         176: 1.826   192: 1.813   208: 1.916   224: 1.898   232: 1.964
+          131 072        192: 3.385   208: 3.393   216: 3.372   224: 3.363
+          1 000 000      158: 14.70   192: 13.84   208: 13.70   224: 13.36   237: 14.17   256: 13.98
+                         (B = 1024: 158: 51.1, 192: 47.7, 208: 47.1, 224: 46.0, 256: 46.2)"""
+        if self.dw_wgs_exact:
+            return min(ncu, self.dw_wgs)
+        want = self.dw_wgs if self.I <= 51200 else max(self.dw_wgs, 192 if self.I <= 100000 else ncu - 32)
+        return max(8, min(ncu, want))
+
+    def _range1_cus(self, plan):
+        """Workgroups of the first time range's forward sweep: the CUs the recurrence of the second range (one workgroup
+        per 4 users) leaves free -- but never under half the chip: with the flat schedule this IS the workgroup count,
+        and at B = 1024 the difference is 0 (8 workgroups swept the whole range: 125 ms instead of 21 at 1M items).
+        Above 51 200 items the whole chip: the sweep then lasts many times the recurrence, which finds its CUs as the
+        sweep's workgroups end (1M items, ms per step at B = 256: 192 -> 13.41, 224 -> 13.04, 256 -> 12.88; at
+        B = 1024: 128 -> 45.5, 192 -> 43.4, 256 -> 43.0; ML-20M shape at B = 1024: 128 / 192 / 256 within 0.5 %)."""
+        if self.range1_cus > 0:
+            return min(self._ncu, self.range1_cus)
+        if self.I > 51200:
+            return self._ncu
+        return max(self._ncu // 2, self._ncu - (plan.B + 3) // 4)
+
     def prepare(self, plan, scoring=False):
         """Build and upload everything the fused step derives from a plan (the work division tables of the
         projection sweeps) BEFORE the step is launched.  Built lazily instead, the upload is a synchronous copy on
@@ -840,7 +909,7 @@ class SVAEEngine:
             return plan
         want = [("rows", None, None, False)] if scoring else [("rows", None, None, None), ("items", None, None, None)]
         if not scoring and self.time_split and plan.split_t > 0:
-            want += [("rows", plan.split_r, self._ncu - (plan.B + 3) // 4, None),
+            want += [("rows", plan.split_r, self._range1_cus(plan), None),
                      ("rows", plan.R - plan.split_r, self._ncu, None)]
         made = [m for m in (self._proj_sched(plan, sd, nx=nx, ncu=ncu, host_only=True, flat=fl) for sd, nx, ncu, fl in want)
                 if m is not None]

@@ -14,6 +14,11 @@ SVAE_DP_REHEARSAL=1 timeout -k 10 200 python -m torch.distributed.run --nnodes=1
   --master-addr 127.0.0.1 --master-port 29516 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline \
   > gpurun_out/dp_rehearsal_rccl.json 2> gpurun_out/dp_rehearsal_rccl.err || { tail -30 gpurun_out/dp_rehearsal_rccl.err; exit 1; }
 cat gpurun_out/dp_rehearsal_rccl.json
+# 1b. the same leg with the collectives through the library's own RCCL wrappers (comm.hip), in stream order
+SVAE_DP_REHEARSAL=1 SVAE_DP_NATIVE=1 timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
+  --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-class \
+  > gpurun_out/dp_rehearsal_rccl_native.json 2> gpurun_out/dp_rehearsal_rccl_native.err || { tail -30 gpurun_out/dp_rehearsal_rccl_native.err; exit 3; }
+cat gpurun_out/dp_rehearsal_rccl_native.json
 SVAE_DIST_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
   --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 3 --nplans 4 --no-cpu-baseline \
   > gpurun_out/dp_rehearsal.json 2> gpurun_out/dp_rehearsal.err || { tail -30 gpurun_out/dp_rehearsal.err; exit 2; }

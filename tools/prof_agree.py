@@ -13,9 +13,17 @@ rows = list(csv.DictReader(open(sys.argv[2])))
 regions = bench.get("ms_per_step_regions", {}).get("n", 1)
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else bench["warmup"] + (regions + 1) * bench["steps"] + bench.get("settle", {}).get("steps", 0) + \
     ((bench.get("roofline") or {}).get("alone", {}).get("steps", -2) + 2)     # the sweeps-alone pass and its 2 warm-up steps
+# the fp32-class leg of the same command launches the <.., true> (split) instantiations of the same templates: not the
+# timed mode, left out here
+rows = [r for r in rows if "true>" not in r["Name"]]
 tot = {}
 for r in rows:
     tot[r["Name"]] = tot.get(r["Name"], 0.0) + float(r["TotalDurationNs"])
+# one weight-gradient sweep per bf16 step (settle, cold figure, warm-up, timed regions, replay, sweeps alone): the
+# trace's own step count
+dw_calls = sum(int(float(r["Calls"])) for r in rows if "proj_kernel<2" in r["Name"])
+if len(sys.argv) <= 3 and dw_calls:
+    steps = dw_calls
 
 
 def trace_ms(*subs):

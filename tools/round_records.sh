@@ -9,7 +9,7 @@ O=$ROOT/gpurun_out
 cd "$ROOT" || exit 1
 mkdir -p "$O"
 bash tools/dp_rehearsal.sh > "$O/dp_rehearsal_$TAG.log" 2>&1 || { tail -20 "$O/dp_rehearsal_$TAG.log"; exit 1; }
-cp "$O/dp_rehearsal_rccl.json" "$O/${TAG}_dp_rehearsal_rccl_world1.json.log"; cp "$O/dp_rehearsal.json" "$O/${TAG}_dp_rehearsal_gloo2.json.log"
+cp "$O/dp_rehearsal_rccl.json" "$O/${TAG}_dp_rehearsal_rccl_world1.json.log"; cp "$O/dp_rehearsal_rccl_native.json" "$O/${TAG}_dp_rehearsal_rccl_native_world1.json.log"; cp "$O/dp_rehearsal.json" "$O/${TAG}_dp_rehearsal_gloo2.json.log"
 # bench.py --gpus 2 spawning its own ranks (no torchrun), gloo on the one card
 SVAE_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 3 --nplans 4 --no-cpu-baseline --repeats 1 > "$O/${TAG}_bench_gpus2_spawn_gloo.json.log" 2> "$O/spawn.err" || { tail -20 "$O/spawn.err"; exit 2; }
 timeout -k 10 300 python tools/epoch_bench.py 2 > "$O/${TAG}_epoch_bench.json" 2> "$O/epoch.err" || { tail -20 "$O/epoch.err"; exit 3; }
