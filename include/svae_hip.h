@@ -398,6 +398,9 @@ int svae_spin(int usec, void* stream);
  * launches are held up behind it (queues that share a dispatcher pipe; engine.py, _pick_concurrent_stream).  No
  * counterpart in the reference. */
 int svae_spin_grid(int usec, int nwg, int lds_bytes, void* stream);
+/* buf[slot] = the device wall clock (100 MHz ticks) when the stream reaches this point (diagnostic: tools/step_stamps.py).
+ * No counterpart in the reference. */
+int svae_stamp(unsigned long long* buf, int slot, void* stream);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,7 @@ SIGNATURES = {
     "svae_mlp_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "svae_spin": [_I, _P],
     "svae_spin_grid": [_I, _I, _I, _P],
+    "svae_stamp": [_P, _I, _P],
     "svae_rccl_unique_id": [_P],
     "svae_rccl_comm_create": [_P, _I, _I, _P],
     "svae_rccl_comm_destroy": [_P],

@@ -1201,6 +1201,16 @@ extern "C" int svae_spin_grid(int usec, int nwg, int lds_bytes, void* stream) {
     return 0;
 }
 
+// One thread writes the device wall clock (100 MHz) into buf[slot]: in-stream time stamps for tools/step_stamps.py (where
+// does the caller's stream wait inside a step -- without a profiler attached, whose launch cost distorts exactly that).
+__global__ void stamp_kernel(unsigned long long* buf, int slot) { buf[slot] = wall_clock64(); }
+extern "C" int svae_stamp(unsigned long long* buf, int slot, void* stream) {
+    SV_CHECK_ARG(buf && slot >= 0, "svae_stamp: bad arguments");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, buf, slot);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
 // Zero fill (replaces the zero_grad pair nb:1197-1198 for the one gradient that is accumulated into, the embedding table's).
 extern "C" int svae_zero(void* p, long long nbytes, void* stream) {
     SV_CHECK_ARG(p && nbytes > 0, "svae_zero: bad arguments");

@@ -175,6 +175,7 @@ class SVAEEngine:
         #  forward 3 -> 0.864, 4 -> 0.864, 5 -> 0.870, 6 -> 0.872, 8 -> 0.883; weight gradient 2 -> 0.866, 3 -> 0.924,
         #  4 -> 0.911)
         self.fdh_q0 = int(_opt("SVAE_FDH_Q0", "4"))  # nominal split count of the forward sweep (_proj_sched)
+        self.stamps = None             # tools/step_stamps.py: dict(buf, names, step)
         self._sevs = {}                # purpose -> _lib.SyncEvent, re-recorded every step
         self._sched_cache = {}         # tile-count shape -> (device table, nwg, ns_q, ns_rem), see _proj_sched
         self.dw_q = int(_opt("SVAE_DW_Q", "2"))      # split count of the weight-gradient sweep (_proj_sched)
@@ -190,6 +191,7 @@ class SVAEEngine:
         self.dw_wgs = int(_opt("SVAE_DW_WGS", "158"))
         self.range1_cus = int(_opt("SVAE_RANGE1_CUS", "0"))           # tuning: workgroups of the first range's forward sweep
         self.dw_wgs_exact = _opt("SVAE_DW_WGS_EXACT", "0") == "1"     # tuning: dw_wgs as given, whatever the shape
+        self.dw_early = _opt("SVAE_DW_EARLY", "1") == "1"      # the weight-gradient sweep starts behind the forward sweep
         self.head_fused = _opt("SVAE_HEAD_FUSED", "1") == "1"
         # bf16 mode: the gathered embedding rows are kept as bf16 (their two consumers -- the input-gate GEMM and the
         # input-weight gradient -- round them to bf16 anyway: bit-identical) -- half the bytes written by the gather,
@@ -333,6 +335,14 @@ class SVAEEngine:
     def _bucket(self, i):
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(i)
+
+    def _stamp(self, name, sp=None):
+        """Diagnostic (tools/step_stamps.py): the device clock when the stream (default: the launch stream) gets here."""
+        d = self.stamps
+        if d is None:
+            return
+        i = d["names"].setdefault(name, len(d["names"]))
+        _lib.call("svae_stamp", d["buf"].data_ptr(), d["step"] * 64 + i, _stream() if sp is None else sp)
 
     def _sev(self, name):
         """The ordering event kept for `name` (one per purpose: a wait refers to the record before it in host order)."""
@@ -546,6 +556,7 @@ class SVAEEngine:
             side = self._side_stream(cur=cur)
             step_begin = self._sev("step_begin")
             step_begin.record(cur)
+        self._stamp("q1 step begins")
         # the caller's stream first: its kernels head the critical path, the side stream's are not needed before the
         # decoder side
         # With a two-range forward (below) only the rows of the first range's timesteps are needed by the recurrence
@@ -618,6 +629,7 @@ class SVAEEngine:
         # kernel trace).
         if t1 > 0:
             gru_range(0, t1, "gru_fwd")
+            self._stamp("q1 recurrence of range 1 done")
             first_done = self._sev("first_done")
             first_done.record(cur)
         else:
@@ -635,6 +647,7 @@ class SVAEEngine:
                     eps_done = True
                 params_ready = self._sev("params_ready")
                 params_ready.record(side)
+                self._stamp("side parameters prepared, noise drawn")
                 if gi_split:
                     # (behind the parameter preparation: the decoder side of the first range waits for that, the
                     #  second recurrence, which needs these rows, only starts when the first one has ended)
@@ -655,8 +668,11 @@ class SVAEEngine:
                                   self.wih_frags[0].data_ptr(), self.P("gru.bias_ih_l0").data_ptr(),
                                   w["gi"].data_ptr() + 4 * G * gi_split, R - gi_split, 0, self.prec, _stream())
                 if t1 > 0:
+                    self._stamp("side input gates of range 2 done")
                     _lib.stream_wait(side, first_done)
+                    self._stamp("side recurrence of range 2 may start")
                     gru_range(t1, plan.Tmax, "gru_fwd2")
+                    self._stamp("side recurrence of range 2 done")
                     if self.mlp2_side and self._w3_event is not None:
                         # the MLP chain of the second range's rows here, behind their recurrence, on the CUs it has
                         # just freed: the caller's stream is still in the first range's sweep (the floated
@@ -664,6 +680,7 @@ class SVAEEngine:
                         _lib.stream_wait(side, self._w3_event)
                     if self.mlp2_side:
                         self._decoder_rows(plan, r1, R, self._ncu, sweep=False)
+                    self._stamp("side MLP chain of range 2 done")
                     second_done = self._sev("second_done")
                     second_done.record(side)
         if eps is None and not eps_done:
@@ -683,9 +700,15 @@ class SVAEEngine:
                 self._float_plan = None       # (kept alive until here: the floated kernels read its tables)
             if t1 > 0:
                 self._last_fused = True
+                self._stamp("q1 decoder side of range 1 may start (parameters, last step's floated work)")
                 self._decoder_rows(plan, 0, r1, self._range1_cus(plan))
+                self._stamp("q1 decoder side of range 1 done")
                 _lib.stream_wait(cur, second_done)
+                self._stamp("q1 sweep of range 2 may start")
                 self._decoder_rows(plan, r1, R, self._ncu, mlp=not self.mlp2_side)
+                self._stamp("q1 sweep of range 2 done")
+                if self.dw_early:
+                    self._sev("fwd_done").record(cur)
                 self._fused_grad = True
                 if defer_loss and self.overlap:
                     self._loss_deferred = True
@@ -715,6 +738,8 @@ class SVAEEngine:
                         w["lse"].data_ptr(), w["dd1"].data_ptr()) + self._proj_sched(plan, "rows")
                 self._split_call("svae_proj_nll_fwd_dh", args, ((1, "proj_fdh_fused"), (2, "proj_fdh_finish")),
                                  strides=(self._ps("rows"), self._ps("items")))
+                if self.dw_early and self.overlap:
+                    self._sev("fwd_done").record(cur)
             else:
                 _lib.call("svae_proj_nll_fwd_split", w["h2s"].data_ptr(), self.w3b.data_ptr(), w["d1"].data_ptr(),
                           self.P("decoder.linear2.weight").data_ptr(), self.P("decoder.linear2.bias").data_ptr(),
@@ -1045,6 +1070,7 @@ class SVAEEngine:
                       w["enc"].data_ptr(), plan.w_kl.data_ptr(), self.mlp_frags.data_ptr(), float(anneal),
                       w["dtmp"].data_ptr(), w["denc"].data_ptr(), w["dhs"].data_ptr(), R, self.prec, st)
             self._toc("mlp_bwd", ev)
+            self._stamp("q1 MLP backward done")
         else:
             self._gemm(w["dd1"], self.P("decoder.linear1.weight"), w["dz"], R, L, DP, DP, L, L, 0, 1)
             _lib.call("svae_latent_bwd", w["tmp"].data_ptr(), w["eps"].data_ptr(), w["dz"].data_ptr(),
@@ -1112,6 +1138,7 @@ class SVAEEngine:
                       self.whh_t.data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(), plan.B, plan.Tmax,
                       dgi.data_ptr(), None if merged else dgh.data_ptr(), self.gru_prec, st)
         self._toc("gru_bwd", ev)
+        self._stamp("q1 BPTT done")
         if side is not None:
             # gated on the chain above, enqueued after the recurrence so that its few workgroups get their CUs
             # first; the weight-gradient kernels then take whatever the recurrence leaves idle
@@ -1119,9 +1146,13 @@ class SVAEEngine:
             floating = self._in_step and self.float_w3 and self._last_fused
             if floating:
                 w3 = self._side_stream(1, cur=cur)
-                _lib.stream_wait(w3, chain_done)
+                # the sweep recomputes the logits from d1, W3 and the row statistics of the forward sweep: it needs
+                # nothing of the MLP backward in front of `chain_done`
+                _lib.stream_wait(w3, self._sev("fwd_done") if self.dw_early else chain_done)
                 with _Launch(w3, self._torch_ctx()):
+                    self._stamp("w3 weight-gradient sweep may start")
                     proj_dw(w["pslabs_side"])
+                    self._stamp("w3 weight-gradient sweep + finish done")
                     # (its bucket's all-reduce is issued by train_step AFTER the other buckets': collectives run in
                     # issue order on RCCL's one stream, and this one, which waits for the sweep, would hold up the
                     # embedding bucket that is ready a hundred microseconds earlier)
@@ -1130,7 +1161,9 @@ class SVAEEngine:
                 if not floating:
                     proj_dw(w["pslabs_side"])
                     self._bucket(0)
+                self._stamp("side dense weight gradients may start")
                 decoder_side_wgrads(self.slabs_side)
+                self._stamp("side dense weight gradients done")
                 if self._loss_deferred:
                     # last on this stream: a one-workgroup kernel that waited 40 us for a free CU beside the sweep
                     # when it came first, with the weight gradients queued behind it.  (Later still -- behind the
@@ -1217,9 +1250,11 @@ class SVAEEngine:
                 (s_, e_), gscale_, count_ = self._early_opt
                 self._adam_range(s_, e_, gscale_, st, count=count_)
                 self._early_opt = False          # (done: train_step leaves this bucket out)
+            self._stamp("q1 dL/demb + scatter-add done")
             _lib.stream_wait(side, bptt_done)
             with _Launch(side, self._torch_ctx()):
                 gru_wgrads()          # (one of the two here and one on the caller's stream: no better, 0.922 vs 0.918)
+                self._stamp("side GRU weight gradients done")
         elif self.tail_embedding_first:
             embedding_grad()
             gru_wgrads()
@@ -1230,6 +1265,7 @@ class SVAEEngine:
             joined = self._sev("side_joined")
             joined.record(side)
             _lib.stream_wait(cur, joined)
+            self._stamp("q1 joined the side stream")
         elif self._loss_deferred:
             _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
@@ -1429,6 +1465,7 @@ class SVAEEngine:
             self._adam_range(rest[0][0], rest[0][1], gscale, cur.cuda_stream)
         else:
             self._adam_range(rest[0][0], rest[-1][1], gscale, cur.cuda_stream)
+            self._stamp("q1 optimizer done", cur.cuda_stream)
         with _Launch(w3, gs is not None):
             if gs is not None:
                 gs.wait(which=[0])
@@ -1441,6 +1478,7 @@ class SVAEEngine:
             else:
                 self._adam_range(s0, e0, gscale, _stream())
             self._proj_prep_items(_stream())
+            self._stamp("w3 optimizer + operand copies of decoder.linear2 done")
         self._w3_event = self._sev("w3")
         self._w3_event.record(w3)
         self._w3_fresh = True
