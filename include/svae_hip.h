@@ -247,6 +247,17 @@ int svae_wgrad_pair_bf16dy(const void* dy, int R, int N, int ldy, int nsplit,
                            int remap_from0, int remap_add0,
                            const void* x1, int x1_bf16, int K1, int ldx1, float* out1, float* colsum1, long long stride1,
                            int remap_from1, int remap_add1, void* stream);
+/* The same two jobs with BOTH X operands as bf16 elements, on 256 x 256 output tiles (one wave per SIMD, 32 MFMAs per
+ * wave and 32-row stage): the form the step's tail uses (x0 = the bf16 copy of the previous hidden states made by
+ * svae_f32_to_bf16).  Same slab layout; the split count may differ from the 128 x 128 kernels' (40 = 240 workgroups, one
+ * round), so results agree with them to fp32 summation order, not bit for bit. */
+int svae_wgrad_pair_big(const void* dy, int R, int N, int ldy, int nsplit,
+                        const void* x0, int K0, int ldx0, float* out0, float* colsum0, long long stride0,
+                        int remap_from0, int remap_add0,
+                        const void* x1, int K1, int ldx1, float* out1, float* colsum1, long long stride1,
+                        int remap_from1, int remap_add1, void* stream);
+/* dst [n] (bf16) = round-to-nearest-even of src [n] (fp32); n a multiple of 8, both 16-byte aligned. */
+int svae_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
 int svae_reduce_slabs_pair(const float* slabs0, float* out0, long long n0, long long stride0, const float* slabs1,
                            float* out1, long long n1, long long stride1, int nsplit, void* stream);
 int svae_rowgemm_ld_prec(const float* x, int ldx, const void* frags, const float* bias, float* y, int R, int which,

@@ -310,6 +310,221 @@ __global__ __launch_bounds__(256) void wgrad_pair_kernel(WgradArgs a0, WgradArgs
     else wgrad_body<true, false, XBF1>(a1, (int)blockIdx.x - n0, smem);
 }
 
+// ---- The all-bf16 form on 256 x 256 tiles (round 3): the GRU's two weight gradients on the step's tail.
+// The 128 x 128 kernel above is bound by its k-loop's per-stage latency (header): a wave has 8 MFMAs (256 pipe cycles) per
+// 32-row stage between two waits and a barrier.  Here a workgroup of 4 waves owns 256 dY columns x 256 X columns, a wave
+// 128 x 128 of it (16 accumulator tiles, 256 registers: one wave per SIMD), and a 32-row stage carries 32 MFMAs per wave
+// (1024 pipe cycles) for the same wait + barrier; operand bytes per output element halve.  An operand is staged as two
+// of the 128-column swizzled images of the kernel above, side by side (a stage: A0 A1 B0 B1, 8 KiB each), filled and read
+// (ds_read_b64_tr_b16) exactly as there.  6 output tiles (3 x 1 per job) x 40 row splits = 240 workgroups: one round.
+constexpr int BIG_T = 256;
+constexpr int BIG_IMG = 32 * 256;              // one 128-column bf16 image of a 32-row stage: 8 KiB
+constexpr int BIG_STAGE = 4 * BIG_IMG;         // 32 KiB
+constexpr int BIG_NST = 4;
+
+__device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const int bid, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 128;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int gsize = a.nx * a.ny, bz = xcd + 8 * (slot / gsize), mem = slot % gsize;
+    if (bz >= a.nz) return;
+    const int bx = mem % a.nx, by = mem / a.nx;
+    const int m0 = by * BIG_T, n0 = bx * BIG_T;
+    const int ntiles = (a.R + 31) / 32;
+    const int t_begin = bz * a.tiles_per_split;          // (32-row tiles here)
+    int t_end = t_begin + a.tiles_per_split;
+    if (t_end > ntiles) t_end = ntiles;
+
+    const __amdgpu_buffer_rsrc_t dyb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((size_t)a.R * a.ldy * 2), BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((size_t)a.R * a.ldx * 2), BUF_FLAGS);
+    // a piece = one wave-instruction = 4 rows of one image; wave w issues rows 4 w .. 4 w + 3 and 16 + the same of all
+    // four images (8 pieces per stage and wave); the lane fetches the chunk that belongs at its LDS position (swz_off)
+    const unsigned rowa = (unsigned)(lane >> 4);
+    const int chs = (lane & 15) ^ (int)((rowa << 2) | (unsigned)wave);
+    const int ca0 = m0 + 8 * chs, ca1 = m0 + 128 + 8 * chs;
+    const unsigned colA0 = (unsigned)(ca0 + (ca0 >= a.remap_from ? a.remap_add : 0)) * 2u,
+                   colA1 = (unsigned)(ca1 + (ca1 >= a.remap_from ? a.remap_add : 0)) * 2u,
+                   colB0 = (unsigned)(n0 + 8 * chs) * 2u, colB1 = (unsigned)(n0 + 128 + 8 * chs) * 2u;
+    const unsigned ldy2 = (unsigned)a.ldy * 2u, ldx2 = (unsigned)a.ldx * 2u;
+#define SV_BIG_LD(rs_, dst_, off_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(dst_), 16, off_, 0, 0, 0);
+#define SV_BIG_STAGE(t_, st_)                                                                                   \
+    {                                                                                                           \
+        char* l_ = smem + (st_) * BIG_STAGE + wave * 1024;                                                       \
+        const unsigned ra_ = ((unsigned)(t_) * 32u + 4u * (unsigned)wave + rowa);                                \
+        SV_BIG_LD(dyb, l_, ra_ * ldy2 + colA0) SV_BIG_LD(dyb, l_ + 4096, (ra_ + 16u) * ldy2 + colA0)             \
+        SV_BIG_LD(dyb, l_ + BIG_IMG, ra_ * ldy2 + colA1) SV_BIG_LD(dyb, l_ + BIG_IMG + 4096, (ra_ + 16u) * ldy2 + colA1) \
+        SV_BIG_LD(xb, l_ + 2 * BIG_IMG, ra_ * ldx2 + colB0) SV_BIG_LD(xb, l_ + 2 * BIG_IMG + 4096, (ra_ + 16u) * ldx2 + colB0) \
+        SV_BIG_LD(xb, l_ + 3 * BIG_IMG, ra_ * ldx2 + colB1) SV_BIG_LD(xb, l_ + 3 * BIG_IMG + 4096, (ra_ + 16u) * ldx2 + colB1) \
+    }
+
+    // (the same offsets serve both operands: a wave's column bases are 32 i in its image)
+    const unsigned tr00 = tr_lane_off(lane, 0, 0), tr01 = tr_lane_off(lane, 0, 1), tr10 = tr_lane_off(lane, 32, 0),
+                   tr11 = tr_lane_off(lane, 32, 1), tr20 = tr_lane_off(lane, 64, 0), tr21 = tr_lane_off(lane, 64, 1),
+                   tr30 = tr_lane_off(lane, 96, 0), tr31 = tr_lane_off(lane, 96, 1);
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // Column sums of dY (the bias gradient), by the workgroups of the first X tile: a thread owns 8 columns (one 16-byte
+    // chunk) of rows rg, rg + 8, rg + 16, rg + 24 of every stage -- four 16-byte LDS reads per stage instead of 32
+    // two-byte ones --, and the eight row groups are summed through LDS once, at the end.
+    const bool do_cs = a.colsum != nullptr && bx == 0;
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cs4 = 0.f, cs5 = 0.f, cs6 = 0.f, cs7 = 0.f;
+    const unsigned cs_c8 = (unsigned)tid & 31u, cs_rg = (unsigned)tid >> 5;
+    const unsigned cs_a0 = (cs_c8 >> 4) * BIG_IMG + swz_off(cs_rg, cs_c8 & 15u), cs_a1 = (cs_c8 >> 4) * BIG_IMG + swz_off(cs_rg + 8u, cs_c8 & 15u),
+                   cs_a2 = (cs_c8 >> 4) * BIG_IMG + swz_off(cs_rg + 16u, cs_c8 & 15u), cs_a3 = (cs_c8 >> 4) * BIG_IMG + swz_off(cs_rg + 24u, cs_c8 & 15u);
+
+    // Software pipeline over half-stages (16 rows = one MFMA k-step): the 16 transposing reads of the NEXT k-step's
+    // fragments are issued one behind each of the 16 MFMAs of the current one (one wave per SIMD: nothing else hides an
+    // LDS read), and the stage's one barrier sits between its two k-steps -- by then every wave holds the stage's second
+    // half in registers, so the stage is refilled at once (tiles t + 1 .. t + 3 in flight while t + 4 is requested).
+    // (Known cost, not yet removed: behind the LDS-read builtins the compiler puts an s_waitcnt vmcnt(0) in front of the
+    //  first read of a phase -- an LDS read it cannot tell apart from the LDS-DMA writes in flight -- which drains the
+    //  prefetch ring at every stage, here and in the 128 x 128 kernels above (llvm-objdump).  proj.hip avoids it with
+    //  inline-asm reads and hand-counted waits; the same change here made the register allocator spill at 100 VGPRs
+    //  -- inline asm with 64-bit outputs beside 256 accumulator registers -- and ran 65 us instead of 36.)
+    bf16x8 ra[4], rb[4], na[4], nb[4];     // the current / next fragments
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    u4v cv0, cv1, cv2, cv3;
+#define SV_BIG_FRAG(r_, i_) r_[i_]
+#define SV_BIG_RD1(da_, db_, i_, t0_, t1_)                                                                       \
+    {                                                                                                           \
+        s4v a0_, a1_, b0_, b1_;                                                                                 \
+        a0_ = tr16(smem + bA_ + t0_); a1_ = tr16(smem + bA_ + t1_);                                               \
+        b0_ = tr16(smem + bB_ + t0_); b1_ = tr16(smem + bB_ + t1_);                                               \
+        da_[i_] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0_, a1_, 0, 1, 2, 3, 4, 5, 6, 7));         \
+        db_[i_] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0_, b1_, 0, 1, 2, 3, 4, 5, 6, 7));         \
+    }
+    // (written out, on scalars: with the offsets in an array and the asm in an unrolled loop the array stayed in scratch
+    //  memory and every read was preceded by a scratch load and a vmcnt(0))
+#define SV_BIG_READS(da_, db_, stg_, ks_)                                                                        \
+    {                                                                                                           \
+        const unsigned bA_ = (unsigned)((stg_) * BIG_STAGE + (wave >> 1) * BIG_IMG + 4096 * (ks_));              \
+        const unsigned bB_ = (unsigned)((stg_) * BIG_STAGE + (2 + (wave & 1)) * BIG_IMG + 4096 * (ks_));         \
+        SV_BIG_RD1(da_, db_, 0, tr00, tr01) SV_BIG_RD1(da_, db_, 1, tr10, tr11)                                  \
+        SV_BIG_RD1(da_, db_, 2, tr20, tr21) SV_BIG_RD1(da_, db_, 3, tr30, tr31)                                  \
+    }
+#define SV_BIG_MFMAS(ca_, cb_)                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                        \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SV_BIG_FRAG(ca_, i_), SV_BIG_FRAG(cb_, j_), acc[i_][j_], 0, 0, 0);
+
+#pragma unroll
+    for (int p = 0; p < BIG_NST - 1; ++p)
+        if (t_begin + p < t_end) SV_BIG_STAGE(t_begin + p, p)
+    if (t_begin < t_end) {
+        // first tile landed (two younger tiles may be in flight)
+        if (t_begin + 2 < t_end) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (t_begin + 1 < t_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t_begin + BIG_NST - 1 < t_end) SV_BIG_STAGE(t_begin + BIG_NST - 1, BIG_NST - 1)
+        SV_BIG_READS(ra, rb, 0, 0)
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+        const int st = (t - t_begin) & (BIG_NST - 1);
+        // k-step 0 of tile t (fragments in ra / rb) beside the reads of its k-step 1 (and of the column sums' chunks)
+        SV_BIG_READS(na, nb, st, 1)
+        {   // (every workgroup: a branch around inline asm here cost 170 registers)
+            const char* cb = smem + st * BIG_STAGE;
+            cv0 = *reinterpret_cast<const u4v*>(cb + cs_a0); cv1 = *reinterpret_cast<const u4v*>(cb + cs_a1);
+            cv2 = *reinterpret_cast<const u4v*>(cb + cs_a2); cv3 = *reinterpret_cast<const u4v*>(cb + cs_a3);
+        }
+        SV_BIG_MFMAS(ra, rb)
+        // tile t + 1 landed?  (two younger tiles may be in flight)
+        if (t + 1 < t_end) {
+            if (t + 3 < t_end) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (t + 2 < t_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();       // every wave holds tile t in registers: its stage is free, tile t + 1 is complete
+        asm volatile("" ::: "memory");
+        if (t + BIG_NST < t_end) SV_BIG_STAGE(t + BIG_NST, st)
+        if (t + 1 < t_end) SV_BIG_READS(ra, rb, (st + 1) & (BIG_NST - 1), 0)
+        SV_BIG_MFMAS(na, nb)
+#define SV_BIG_CSADD(v_)                                                                                         \
+        cs0 += __uint_as_float(v_.x << 16); cs1 += __uint_as_float(v_.x & 0xFFFF0000u);                          \
+        cs2 += __uint_as_float(v_.y << 16); cs3 += __uint_as_float(v_.y & 0xFFFF0000u);                          \
+        cs4 += __uint_as_float(v_.z << 16); cs5 += __uint_as_float(v_.z & 0xFFFF0000u);                          \
+        cs6 += __uint_as_float(v_.w << 16); cs7 += __uint_as_float(v_.w & 0xFFFF0000u);
+        SV_BIG_CSADD(cv0) SV_BIG_CSADD(cv1) SV_BIG_CSADD(cv2) SV_BIG_CSADD(cv3)
+#undef SV_BIG_CSADD
+    }
+#undef SV_BIG_FRAG
+#undef SV_BIG_READS
+#undef SV_BIG_RD1
+#undef SV_BIG_MFMAS
+#undef SV_BIG_STAGE
+#undef SV_BIG_LD
+
+    float* C = a.out + (size_t)bz * a.slab_stride;
+    if (do_cs) {
+        // sum the eight row groups' partial column sums through LDS (the stages are free: every wave is past its last read)
+        __builtin_amdgcn_s_barrier();
+        float* red = reinterpret_cast<float*>(smem);           // [8 row groups][256 columns]
+        float* rp = red + cs_rg * 256 + 8 * cs_c8;
+        rp[0] = cs0; rp[1] = cs1; rp[2] = cs2; rp[3] = cs3; rp[4] = cs4; rp[5] = cs5; rp[6] = cs6; rp[7] = cs7;
+        __builtin_amdgcn_s_barrier();
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) sum += red[g * 256 + tid];
+        if (m0 + tid < a.N) (a.colsum + (size_t)bz * a.slab_stride)[m0 + tid] = sum;
+    }
+    // C layout of a 32x32 tile: col = lane&31 -> X column, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> dY column.  A 32-row
+    // group that lies inside N is stored without per-element checks (N = 672 = 21 groups: always, for the GRU).
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn + 32 * j + li;
+        if (n >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mb = m0 + wm + 32 * i + 4 * lh;
+            if (m0 + wm + 32 * i + 31 < a.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) C[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * a.K + n] = acc[i][j][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < a.N) C[(size_t)m * a.K + n] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_big_pair_kernel(WgradArgs a0, WgradArgs a1, int n0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the job's arguments selected field by field (scalar selects): with the body called on a0 or a1 by reference the
+    // compiler kept the structure in scratch memory and re-read its fields inside the loop
+    const bool f = (int)blockIdx.x < n0;
+    WgradArgs a;
+    a.dy = f ? a0.dy : a1.dy; a.x = f ? a0.x : a1.x; a.out = f ? a0.out : a1.out; a.colsum = f ? a0.colsum : a1.colsum;
+    a.R = a0.R; a.N = a0.N; a.K = f ? a0.K : a1.K; a.ldy = a0.ldy; a.ldx = f ? a0.ldx : a1.ldx;
+    a.nx = f ? a0.nx : a1.nx; a.ny = a0.ny; a.nz = a0.nz; a.tiles_per_split = a0.tiles_per_split;
+    a.slab_stride = f ? a0.slab_stride : a1.slab_stride;
+    a.remap_from = f ? a0.remap_from : a1.remap_from; a.remap_add = f ? a0.remap_add : a1.remap_add;
+    wgrad_big_body(a, f ? (int)blockIdx.x : (int)blockIdx.x - n0, smem);
+}
+
+// dst[i] = bf16(src[i]) (RNE), n a multiple of 8: the bf16 copy of the recurrence's previous hidden states that the
+// all-bf16 weight-gradient kernels read (they round to bf16 anyway: the products are bit-identical).
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const float4 u = reinterpret_cast<const float4*>(src)[2 * i], v = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        uint4 o;
+        o.x = pk2(u.x, u.y); o.y = pk2(u.z, u.w); o.z = pk2(v.x, v.y); o.w = pk2(v.z, v.w);
+        reinterpret_cast<uint4*>(dst)[i] = o;
+    }
+}
+
 // out_j[i] = sum over job j's slabs, both jobs in one launch (blocks [0, b0): job 0); 8 slabs in flight, fixed order
 __global__ void reduce_slabs_pair_kernel(const float* __restrict__ s0, float* __restrict__ o0, long long n40,
                                          long long stride0, const float* __restrict__ s1, float* __restrict__ o1,
@@ -488,6 +703,56 @@ extern "C" int svae_reduce_slabs_pair(const float* slabs0, float* out0, long lon
     if (b1 > 1024) b1 = 1024;
     hipLaunchKernelGGL(reduce_slabs_pair_kernel, dim3(b0 + b1), dim3(256), 0, (hipStream_t)stream, slabs0, out0, n40, stride0,
                        slabs1, out1, n41, stride1, nsplit, b0);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// No single counterpart in the reference: svae_wgrad_pair_bf16dy with BOTH X operands as bf16 elements, on 256 x 256
+// tiles (wgrad_big_body).  x0 / x1 [R][ldx] bf16 (ldx multiples of 8); slabs as in the pair launch above (sum them with
+// svae_reduce_slabs_pair); nsplit a multiple of 8 is best (workgroups = 8 ceil(nsplit / 8) x tiles per job).
+extern "C" int svae_wgrad_pair_big(const void* dy, int R, int N, int ldy, int nsplit,
+                                   const void* x0, int K0, int ldx0, float* out0, float* colsum0, long long stride0,
+                                   int remap_from0, int remap_add0,
+                                   const void* x1, int K1, int ldx1, float* out1, float* colsum1, long long stride1,
+                                   int remap_from1, int remap_add1, void* stream) {
+    SV_CHECK_ARG(dy && x0 && x1 && out0 && out1, "svae_wgrad_pair_big: null pointer");
+    SV_CHECK_ARG(R > 0 && N > 0 && K0 > 0 && K1 > 0 && ldy >= N && ldx0 >= K0 && ldx1 >= K1 && nsplit >= 1,
+                 "svae_wgrad_pair_big: bad shape");
+    SV_CHECK_ARG((ldy % 8) == 0 && (ldx0 % 8) == 0 && (ldx1 % 8) == 0 && (remap_from0 % 8) == 0 && (remap_add0 % 8) == 0 &&
+                     (remap_from1 % 8) == 0 && (remap_add1 % 8) == 0 && remap_add0 >= 0 && remap_add1 >= 0 &&
+                     N + remap_add0 <= ldy && N + remap_add1 <= ldy,
+                 "svae_wgrad_pair_big: bad alignment / remap");
+    SV_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)x0 % 16) == 0 && ((uintptr_t)x1 % 16) == 0,
+                 "svae_wgrad_pair_big: operands must be 16-byte aligned");
+    SV_CHECK_ARG((long long)R * ldy * 2 < (1ll << 32) && (long long)R * ldx0 * 2 < (1ll << 32) && (long long)R * ldx1 * 2 < (1ll << 32),
+                 "svae_wgrad_pair_big: operand larger than a 4 GiB buffer descriptor");
+    SV_CHECK_ARG(stride0 >= (long long)N * K0 && stride1 >= (long long)N * K1, "svae_wgrad_pair_big: bad slab stride");
+    const int n32 = (R + 31) / 32, tps = (n32 + nsplit - 1) / nsplit;
+    WgradArgs a0{(const float*)dy, (const float*)x0, out0, colsum0, R, N, K0, ldy, ldx0, (K0 + BIG_T - 1) / BIG_T,
+                 (N + BIG_T - 1) / BIG_T, nsplit, tps, stride0, remap_from0, remap_add0};
+    WgradArgs a1{(const float*)dy, (const float*)x1, out1, colsum1, R, N, K1, ldy, ldx1, (K1 + BIG_T - 1) / BIG_T,
+                 (N + BIG_T - 1) / BIG_T, nsplit, tps, stride1, remap_from1, remap_add1};
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_big_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           BIG_NST * BIG_STAGE);
+        if (e != hipSuccess) return svae_fail((int)e, "svae_wgrad_pair_big: LDS attribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int z8 = 8 * ((nsplit + 7) / 8);
+    const int n0 = z8 * a0.nx * a0.ny, n1 = z8 * a1.nx * a1.ny;
+    hipLaunchKernelGGL(wgrad_big_pair_kernel, dim3(n0 + n1), dim3(256), BIG_NST * BIG_STAGE, (hipStream_t)stream, a0, a1, n0);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst [n] bf16 = RNE(src [n] fp32); n a multiple of 8, both 16-byte aligned.
+extern "C" int svae_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
+    SV_CHECK_ARG(src && dst && n > 0 && (n % 8) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                 "svae_f32_to_bf16: bad arguments");
+    long long nb = (n / 8 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n / 8);
     SV_LAUNCH_CHECK();
     return 0;
 }

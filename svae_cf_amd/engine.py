@@ -121,11 +121,17 @@ class SVAEEngine:
         # row splits of the weight-gradient GEMMs (end of round 2, tools/sweep_env.sh, ms per step on one box, two
         # rounds: 32 -> 0.868 / 0.870, 16 -> 0.867 / 0.870, 24 -> 0.868 / 0.869, 21 -> 0.881 / 0.879, 48 -> 0.883 / 0.881)
         self.nsplit = int(_opt("SVAE_NSPLIT", "32"))
-        self.slabs = torch.zeros(self.nsplit * (G * E + G), **f32)        # largest split-K output: dW_ih
+        # The GRU's two weight gradients on 256 x 256 tiles (svae_wgrad_pair_big): 36 us against 48 alone at 21.8k rows, but
+        # NOT in the step -- 0.8475 against 0.8460 ms, two alternating pairs: its workgroups take a whole CU (128 KB of
+        # LDS, one wave per SIMD) and wait for the CUs the weight-gradient sweep holds, where the 128 x 128 kernel's
+        # fit in beside the sweep's.  Off; kept as a library entry point with its test (tests/test_gpu_wgrad.py).
+        self.wgrad_big = _opt("SVAE_WGRAD_BIG", "0") == "1"
+        self.nsplit_big = 40                                       # (6 output tiles x 40 row splits = 240 workgroups)
+        self.slabs = torch.zeros(max(self.nsplit, self.nsplit_big) * (G * E + G), **f32)        # largest split-K output: dW_ih
         self.slabs_side = torch.zeros(self.nsplit * (DP * HP + DP), **f32)  # side-stream weight gradients
         # dW_hh's own slabs: the paired launch of the two GRU weight gradients (and the two-range BPTT) keep them
         # pending beside dW_ih's
-        self.slabs_hh = torch.zeros(self.nsplit * (G * HP + G), **f32)
+        self.slabs_hh = torch.zeros(max(self.nsplit, self.nsplit_big) * (G * HP + G), **f32)
         self.dh_carry = None
         # Backward runs on two streams: the data-gradient chain that leads to the GRU's BPTT (a 16-64 CU kernel,
         # latency bound) stays on the caller's stream, the decoder-side weight gradients (whole-GPU kernels that
@@ -278,6 +284,7 @@ class SVAEEngine:
             self.capp = capp
             self.ws["dg4b"] = torch.zeros((cap + 1) * 4 * HP, **bf)
             self.ws["emb16"] = torch.zeros((cap + 1) * E, **bf)       # the gathered rows as bf16 (self.emb16)
+            self.ws["hprev16"] = torch.zeros((cap + 1) * HP, **bf)    # the previous hidden states as bf16 (self.wgrad_big)
             # (split instantiation: every bf16 image is followed by its mid and lo parts, one part stride apart)
             m = 3 if self.split else 1
             self.ws["h2b"] = torch.zeros(m * capp * DP, **bf)
@@ -1162,6 +1169,10 @@ class SVAEEngine:
                     proj_dw(w["pslabs_side"])
                     self._bucket(0)
                 self._stamp("side dense weight gradients may start")
+                if self._big_wgrads(dg16):
+                    # the bf16 copy of the previous hidden states for the 256-tile weight-gradient kernel: here, beside
+                    # the BPTT, where this stream has time (5 us; the kernel rounds to bf16 anyway: same products)
+                    _lib.call("svae_f32_to_bf16", w["hprev"].data_ptr(), w["hprev16"].data_ptr(), R * HP, _stream())
                 decoder_side_wgrads(self.slabs_side)
                 self._stamp("side dense weight gradients done")
                 if self._loss_deferred:
@@ -1209,6 +1220,20 @@ class SVAEEngine:
             # kernel trace shows the caller's queue busy 898 of a step's 971 us -- it is the critical path, and by the
             # end of the BPTT the side stream has been idle for ~70 us.)
             ns = max(1, min(self.nsplit, (R + 127) // 128))
+            if self._big_wgrads(dg16) and side is not None and not tb:
+                # both on 256 x 256 tiles, all operands bf16 (svae_wgrad_pair_big: 36 us against 48 alone at 21.8k rows)
+                nb = max(2, min(self.nsplit_big, (R + 255) // 256))
+                o_hh = self._gbase + 4 * self.layout.offset("gru.weight_hh_l0")
+                o_ih = self._gbase + 4 * self.layout.offset("gru.weight_ih_l0")
+                s_hh, s_ih = self.slabs_hh.data_ptr(), self.slabs.data_ptr()
+                st_hh, st_ih = G * HP + G, G * E + G
+                ev = self._tic("wgrad")
+                _lib.call("svae_wgrad_pair_big", dgi.data_ptr(), R, G, ldg, nb,
+                          w["hprev16"].data_ptr(), HP, HP, s_hh, s_hh + 4 * G * HP, st_hh, hh_remap[0], hh_remap[1],
+                          w["emb16"].data_ptr(), E, E, s_ih, s_ih + 4 * G * E, st_ih, (G + 7) // 8 * 8, 0, _stream())
+                _lib.call("svae_reduce_slabs_pair", s_hh, o_hh, st_hh, st_hh, s_ih, o_ih, st_ih, st_ih, nb, _stream())
+                self._toc("wgrad", ev)
+                return
             if self.wgrad_pair and dg16 and self.fused and ns > 1:
                 # both in ONE launch and their slabs summed by ONE reduce (svae_wgrad_pair_bf16dy): the same workgroups
                 # writing the same slabs, one kernel boundary and one reduce less on the tail's side chain
@@ -1271,6 +1296,12 @@ class SVAEEngine:
                       plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
         self._loss_deferred = False
         self._bucket(1)      # dense layers (side stream) + GRU (this stream): behind the join
+
+    def _big_wgrads(self, dg16):
+        """The GRU's weight gradients take the 256 x 256-tile kernel: bf16 gradient array, bf16 embedding rows, the
+        overlapped step (the bf16 copy of the hidden states is made on the side stream)."""
+        return bool(self.wgrad_big and dg16 and self._emb16_live and self.fused and self.overlap and self.wgrad_pair
+                    and self.gru_wgrad_side and not self.bptt_split)
 
     def _tail_two_ranges(self, plan, cur, side, late_done, dg, ldg, rb, hh_remap):
         """Tail of backward with a two-range BPTT (bf16 gradient array dg [R][ldg]): rows >= rb were final at

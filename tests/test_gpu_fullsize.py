@@ -161,18 +161,20 @@ def test_gru_gradient_array_forms_agree():
     (dr, dz, dn, dn*r) or as that array in bf16.  Every MFMA consumer rounds them to bf16 (RNE) before multiplying,
     so the three forms must give BIT-IDENTICAL weight and embedding gradients; the two GRU bias gradients are column
     sums of the array itself and differ by the bf16 rounding of their terms in the third form (<= 1e-3 of the
-    largest entry; measured 2e-4)."""
+    largest entry; measured 2e-4).  A fourth run takes the 256 x 256-tile kernel for the GRU's weight gradients (engine.wgrad_big,
+    bf16 hidden states): equal to fp32 summation order."""
     import svae_cf_amd as S
     from svae_cf_amd import synth
     I, B = 3000, 64
     users = synth.make_users(B, I, 3.6, 0.6, 120, seed=11)
     plan = S.build_plan(users, 4, user_keys=np.arange(B), device="cuda", total_items=I)
     grads = []
-    for merged, bf16 in ((False, False), (True, False), (True, True)):
+    for merged, bf16, big in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
         eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
         torch.manual_seed(1)
         eng.load_state_dict({n: torch.randn(s) * 0.1 for n, s in eng.layout.ref_shapes.items()})
         eng.merged_dg, eng.dg_bf16 = merged, bf16
+        eng.wgrad_big = big        # (the 256 x 256-tile kernel sums in another order: compared separately below)
         eng.forward(plan, 0.05, seed=3, step=1)
         eng.backward()
         torch.cuda.synchronize()
@@ -185,6 +187,10 @@ def test_gru_gradient_array_forms_agree():
             assert d <= 1e-3 * float(grads[1][k].abs().max()), (k, d)
         else:
             assert torch.equal(grads[1][k], grads[2][k]), ("merged bf16 array", k)
+        # the alternative form (engine.wgrad_big): the GRU's two weight gradients on 256 x 256 tiles with a bf16 copy of the hidden states --
+        # the same bf16 products, another summation order (tiles, split count)
+        d = float((grads[2][k] - grads[3][k]).abs().max())
+        assert d <= 3e-6 * float(grads[2][k].abs().max()), ("256-tile weight gradients", k, d)
 
 
 def test_fused_operand_copies_equal_the_two_kernel_path():
@@ -248,6 +254,7 @@ def test_step_order_options_leave_the_step_bit_identical():
         _init(eng, 5)
         eng.head_fused, eng.mlp2_side, eng.emb16 = head, mlp2, e16
         eng.wgrad_pair = pair      # the two GRU weight gradients in one launch (svae_wgrad_pair_bf16dy) or in two
+        eng.wgrad_big = False      # (the 256 x 256-tile kernel sums in another order: test_gru_gradient_array_forms_agree)
         eng.prepare(plan)
         losses = []
         for s in range(3):

@@ -123,3 +123,47 @@ def test_wgrad_pair_equals_the_two_single_launches(x1_bf16, R, ns):
     o0, o1 = o0.cpu().numpy(), o1.cpu().numpy()
     assert np.array_equal(o0[: N * K0].reshape(N, K0), a[0]) and np.array_equal(o0[N * K0:], a[1])
     assert np.array_equal(o1[: N * K1].reshape(N, K1), b[0]) and np.array_equal(o1[N * K1:], b[1])
+
+
+@pytest.mark.parametrize("R,ns", [(333, 3), (4099, 40), (21814, 40)])
+def test_wgrad_pair_on_256_tiles_equals_the_128_tile_kernels(R, ns):
+    """svae_wgrad_pair_big (both X operands bf16, 256 x 256 tiles) against svae_wgrad_pair_bf16dy on the same operands:
+    the same bf16 products, another summation order (tile shape and split count): 2e-6 of the result's scale; and the
+    bf16 copy svae_f32_to_bf16 makes is torch's (round to nearest even), bit for bit."""
+    N, ldy, K0, K1 = 672, 896, 224, 256
+    g = torch.Generator(device="cuda").manual_seed(R)
+    dy = (torch.randn(R + 3, ldy, device="cuda", generator=g) * 0.1).bfloat16()
+    x0 = torch.randn(R + 3, K0, device="cuda", generator=g)
+    x1 = torch.randn(R + 3, K1, device="cuda", generator=g).bfloat16()
+    st = torch.cuda.current_stream().cuda_stream
+    x0b = torch.empty(R + 3, K0, device="cuda", dtype=torch.bfloat16)
+    _lib.call("svae_f32_to_bf16", x0.data_ptr(), x0b.data_ptr(), (R + 3) * K0, st)
+    assert torch.equal(x0b, x0.bfloat16())
+    r0, r1 = (448, 224), (672, 0)
+    st0, st1 = N * K0 + N, N * K1 + N
+
+    def run(big, ns_):
+        s0 = torch.full((ns_ * st0,), float("nan"), device="cuda")
+        s1 = torch.full((ns_ * st1,), float("nan"), device="cuda")
+        o0, o1 = torch.empty(st0, device="cuda"), torch.empty(st1, device="cuda")
+        if big:
+            _lib.call("svae_wgrad_pair_big", dy.data_ptr(), R, N, ldy, ns_,
+                      x0b.data_ptr(), K0, K0, s0.data_ptr(), s0.data_ptr() + 4 * N * K0, st0, r0[0], r0[1],
+                      x1.data_ptr(), K1, K1, s1.data_ptr(), s1.data_ptr() + 4 * N * K1, st1, r1[0], r1[1], st)
+        else:
+            _lib.call("svae_wgrad_pair_bf16dy", dy.data_ptr(), R, N, ldy, ns_,
+                      x0.data_ptr(), K0, K0, s0.data_ptr(), s0.data_ptr() + 4 * N * K0, st0, r0[0], r0[1],
+                      x1.data_ptr(), 1, K1, K1, s1.data_ptr(), s1.data_ptr() + 4 * N * K1, st1, r1[0], r1[1], st)
+        _lib.call("svae_reduce_slabs_pair", s0.data_ptr(), o0.data_ptr(), st0, st0, s1.data_ptr(), o1.data_ptr(), st1, st1, ns_, st)
+        torch.cuda.synchronize()
+        return o0.double(), o1.double()
+    a0, a1 = run(False, min(ns, 32))
+    b0, b1 = run(True, ns)
+    assert torch.isfinite(b0).all() and torch.isfinite(b1).all()
+    for a, b in ((a0, b0), (a1, b1)):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), float((a - b).abs().max() / a.abs().max())
+    # and against fp64 on the bf16-rounded operands (what both compute)
+    dyf = dy[:R].double()
+    cols = torch.cat([torch.arange(448), torch.arange(448, 672) + 224]).cuda()
+    ref0 = dyf[:, cols].t() @ x0b[:R].double()
+    assert float((b0[: N * K0].reshape(N, K0) - ref0).abs().max()) <= 1e-5 * float(ref0.abs().max())
