@@ -248,8 +248,9 @@ int svae_wgrad_pair_bf16dy(const void* dy, int R, int N, int ldy, int nsplit,
                            const void* x1, int x1_bf16, int K1, int ldx1, float* out1, float* colsum1, long long stride1,
                            int remap_from1, int remap_add1, void* stream);
 /* The same two jobs with BOTH X operands as bf16 elements, on 256 x 256 output tiles (one wave per SIMD, 32 MFMAs per
- * wave and 32-row stage): the form the step's tail uses (x0 = the bf16 copy of the previous hidden states made by
- * svae_f32_to_bf16).  Same slab layout; the split count may differ from the 128 x 128 kernels' (40 = 240 workgroups, one
+ * wave and 32-row stage); x0 = the bf16 copy of the previous hidden states made by svae_f32_to_bf16.  Faster than the
+ * pair launch above alone (36 against 48 us at 21.8k rows), not inside the engine's step (its workgroups need a whole
+ * CU each), so the engine takes it only on request (SVAEEngine.wgrad_big).  Same slab layout; the split count may differ from the 128 x 128 kernels' (40 = 240 workgroups, one
  * round), so results agree with them to fp32 summation order, not bit for bit. */
 int svae_wgrad_pair_big(const void* dy, int R, int N, int ldy, int nsplit,
                         const void* x0, int K0, int ldx0, float* out0, float* colsum0, long long stride0,
