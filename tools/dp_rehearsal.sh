@@ -19,7 +19,11 @@ SVAE_DP_REHEARSAL=1 SVAE_DP_NATIVE=1 timeout -k 10 200 python -m torch.distribut
   --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-class \
   > gpurun_out/dp_rehearsal_rccl_native.json 2> gpurun_out/dp_rehearsal_rccl_native.err || { tail -30 gpurun_out/dp_rehearsal_rccl_native.err; exit 3; }
 cat gpurun_out/dp_rehearsal_rccl_native.json
-SVAE_DIST_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-  --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 3 --nplans 4 --no-cpu-baseline \
-  > gpurun_out/dp_rehearsal.json 2> gpurun_out/dp_rehearsal.err || { tail -30 gpurun_out/dp_rehearsal.err; exit 2; }
+[ "$1" == "rccl-only" ] && exit 0
+# (two processes on one card: on some boxes of the pool they are time-sliced with a long quantum -- 500 ms per step instead
+#  of 15 -- so this leg is bounded and its failure is reported, not fatal to the caller)
+echo "gloo leg: two ranks on the one card"
+SVAE_DIST_BACKEND=gloo timeout -k 10 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+  --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 6 --warmup 2 --settle-steps 4 --nplans 4 --no-cpu-baseline --no-fp32-class --no-cold-figure \
+  > gpurun_out/dp_rehearsal.json 2> gpurun_out/dp_rehearsal.err || { tail -5 gpurun_out/dp_rehearsal.err; echo "gloo leg failed or timed out"; exit 2; }
 cat gpurun_out/dp_rehearsal.json
