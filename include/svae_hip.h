@@ -257,6 +257,15 @@ int svae_wgrad_pair_big(const void* dy, int R, int N, int ldy, int nsplit,
                         int remap_from0, int remap_add0,
                         const void* x1, int K1, int ldx1, float* out1, float* colsum1, long long stride1,
                         int remap_from1, int remap_add1, void* stream);
+/* svae_wgrad_pair_bf16dy with BOTH X operands as bf16 elements (x0: the bf16 copy of the previous hidden states), on the
+ * all-bf16 128 x 128 kernel with hand-counted waits (no drain of the LDS-DMA ring at every stage): same workgroups and
+ * slabs as the pair launch; weight gradients bit-identical to svae_wgrad_cols_bf16dy_bf16x's, bias gradients equal to
+ * summation order. */
+int svae_wgrad_pair_bf16(const void* dy, int R, int N, int ldy, int nsplit,
+                         const void* x0, int K0, int ldx0, float* out0, float* colsum0, long long stride0,
+                         int remap_from0, int remap_add0,
+                         const void* x1, int K1, int ldx1, float* out1, float* colsum1, long long stride1,
+                         int remap_from1, int remap_add1, void* stream);
 /* dst [n] (bf16) = round-to-nearest-even of src [n] (fp32); n a multiple of 8, both 16-byte aligned. */
 int svae_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
 int svae_reduce_slabs_pair(const float* slabs0, float* out0, long long n0, long long stride0, const float* slabs1,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "svae_wgrad_cols_bf16dy_bf16x": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _LL, _I, _I, _P],
     "svae_wgrad_pair_big": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _LL, _I, _I, _P, _I, _I, _P, _P, _LL, _I, _I, _P],
     "svae_f32_to_bf16": [_P, _P, _LL, _P],
+    "svae_wgrad_pair_bf16": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _LL, _I, _I, _P, _I, _I, _P, _P, _LL, _I, _I, _P],
     "svae_wgrad_pair_bf16dy": [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _LL, _I, _I, _P, _I, _I, _I, _P, _P, _LL, _I, _I, _P],
     "svae_reduce_slabs_pair": [_P, _P, _LL, _LL, _P, _P, _LL, _LL, _I, _P],
     "svae_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _F, _P],

@@ -310,6 +310,165 @@ __global__ __launch_bounds__(256) void wgrad_pair_kernel(WgradArgs a0, WgradArgs
     else wgrad_body<true, false, XBF1>(a1, (int)blockIdx.x - n0, smem);
 }
 
+// ---- The all-bf16 form with LDS reads the compiler does not see (round 3): wgrad_body<true, false, true> -- same tiles,
+// same stages, same MFMA order, bit-identical weight gradients -- with its fragment reads as inline asm.  Behind the
+// builtin reads the compiler puts an s_waitcnt vmcnt(0) in front of the first LDS read of every stage (it cannot tell the
+// read from the LDS-DMA writes in flight): the prefetch ring of three tiles is drained at every stage, the tile requested a
+// moment ago included.  Here the waits are hand-counted: vmcnt for the stage's own pieces in front of the barrier,
+// lgkmcnt in front of each k-step's MFMAs (LDS returns in order).  Column sums: a thread owns one 16-byte chunk (8
+// columns) of rows rg and rg + 16 -- two 16-byte reads per stage instead of 32 two-byte ones --, the 16 row groups are
+// summed through LDS at the end (another summation order than wgrad_body's: the bias gradients agree to rounding).
+__device__ __forceinline__ void wgrad16_body(const WgradArgs& a, const int bid, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int gsize = a.nx * a.ny, bz = xcd + 8 * (slot / gsize), mem = slot % gsize;
+    if (bz >= a.nz) return;
+    const int bx = mem % a.nx, by = mem / a.nx;
+    const int m0 = by * WM, n0 = bx * WN;
+    const int ntiles = (a.R + 31) / 32;
+    const int tps = a.tiles_per_split / 2;             // (a.tiles_per_split counts 16-row tiles)
+    const int t_begin = bz * tps;
+    int t_end = t_begin + tps;
+    if (t_end > ntiles) t_end = ntiles;
+
+    const __amdgpu_buffer_rsrc_t dyb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((size_t)a.R * a.ldy * 2), BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((size_t)a.R * a.ldx * 2), BUF_FLAGS);
+    const unsigned rowa = (unsigned)(lane >> 4);
+    const int chs = (lane & 15) ^ (int)((rowa << 2) | (unsigned)wave);
+    const int ca = m0 + 8 * chs;
+    const unsigned colA = (unsigned)(ca + (ca >= a.remap_from ? a.remap_add : 0)) * 2u, colB = (unsigned)(n0 + 8 * chs) * 2u;
+    const unsigned ldy2 = (unsigned)a.ldy * 2u, ldx2 = (unsigned)a.ldx * 2u;
+#define SV_W16_LD(rs_, dst_, off_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(dst_), 16, off_, 0, 0, 0);
+#define SV_W16_STAGE(t_, st_)                                                                                   \
+    {                                                                                                           \
+        char* l_ = smem + (st_) * STAGE_BYTES + wave * 1024;                                                     \
+        const unsigned ra_ = ((unsigned)(t_) * 32u + 4u * (unsigned)wave + rowa);                                \
+        SV_W16_LD(dyb, l_, ra_ * ldy2 + colA) SV_W16_LD(dyb, l_ + 4096, (ra_ + 16u) * ldy2 + colA)               \
+        SV_W16_LD(xb, l_ + TILE_BYTES, ra_ * ldx2 + colB) SV_W16_LD(xb, l_ + TILE_BYTES + 4096, (ra_ + 16u) * ldx2 + colB) \
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    // fragment (i = 0, 1; half h) offsets inside a k-step's image, for the A tile (column base wm + 32 i) and the B tile
+    const unsigned tA00 = tr_lane_off(lane, wm, 0), tA01 = tr_lane_off(lane, wm, 1), tA10 = tr_lane_off(lane, wm + 32, 0),
+                   tA11 = tr_lane_off(lane, wm + 32, 1), tB00 = tr_lane_off(lane, wn, 0), tB01 = tr_lane_off(lane, wn, 1),
+                   tB10 = tr_lane_off(lane, wn + 32, 0), tB11 = tr_lane_off(lane, wn + 32, 1);
+    const unsigned cs_c8 = (unsigned)tid & 15u, cs_rg = (unsigned)tid >> 4;
+    const unsigned cs_a0 = swz_off(cs_rg, cs_c8), cs_a1 = swz_off(cs_rg + 16u, cs_c8);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cs4 = 0.f, cs5 = 0.f, cs6 = 0.f, cs7 = 0.f;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (t_begin + p < t_end) SV_W16_STAGE(t_begin + p, p)
+
+#define SV_W16_RD(d_, base_, o0_, o1_)                                                                           \
+    {                                                                                                           \
+        s4v h0_, h1_;                                                                                           \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h0_) : "v"((base_) + (o0_)));                            \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h1_) : "v"((base_) + (o1_)));                            \
+        d_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0_, h1_, 0, 1, 2, 3, 4, 5, 6, 7));              \
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+        const int st = (t - t_begin) & (NST - 1);
+        // own pieces of tile t landed (4 per tile and wave; tiles t + 1, t + 2 may still be in flight)
+        if (t + 2 < t_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // tile t complete; everyone is done reading tile t - 1's stage
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < t_end) SV_W16_STAGE(t + NST - 1, (st + NST - 1) & (NST - 1))
+        const unsigned sA = lds0 + (unsigned)(st * STAGE_BYTES), sB = sA + TILE_BYTES;
+        bf16x8 a00, a01, b00, b01, a10, a11, b10, b11;      // [k-step][i]
+        u4v c0, c1;
+        SV_W16_RD(a00, sA, tA00, tA01) SV_W16_RD(a01, sA, tA10, tA11)
+        SV_W16_RD(b00, sB, tB00, tB01) SV_W16_RD(b01, sB, tB10, tB11)
+        SV_W16_RD(a10, sA + 4096u, tA00, tA01) SV_W16_RD(a11, sA + 4096u, tA10, tA11)
+        SV_W16_RD(b10, sB + 4096u, tB00, tB01) SV_W16_RD(b11, sB + 4096u, tB10, tB11)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(c0) : "v"(sA + cs_a0));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(c1) : "v"(sA + cs_a1));
+        // 18 reads in flight, returned in order: the first k-step's 8 are there when 10 remain
+        asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(a00), "+v"(a01), "+v"(b00), "+v"(b01));
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b00, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a00, b01, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, b00, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a01, b01, acc[1][1], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a10), "+v"(a11), "+v"(b10), "+v"(b11));
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, b10, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, b11, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b10, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, b11, acc[1][1], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1));
+#define SV_W16_CSADD(v_)                                                                                         \
+        cs0 += __uint_as_float(v_.x << 16); cs1 += __uint_as_float(v_.x & 0xFFFF0000u);                          \
+        cs2 += __uint_as_float(v_.y << 16); cs3 += __uint_as_float(v_.y & 0xFFFF0000u);                          \
+        cs4 += __uint_as_float(v_.z << 16); cs5 += __uint_as_float(v_.z & 0xFFFF0000u);                          \
+        cs6 += __uint_as_float(v_.w << 16); cs7 += __uint_as_float(v_.w & 0xFFFF0000u);
+        SV_W16_CSADD(c0) SV_W16_CSADD(c1)
+#undef SV_W16_CSADD
+    }
+#undef SV_W16_RD
+#undef SV_W16_STAGE
+#undef SV_W16_LD
+
+    float* C = a.out + (size_t)bz * a.slab_stride;
+    if (a.colsum != nullptr && bx == 0) {
+        // (__syncthreads, not the bare s_barrier builtin: that one is no memory fence to the compiler, which moved the
+        //  reads of `red` across it -- bias gradients that changed from run to run, found by tools/probe/soak_which.py)
+        __syncthreads();                       // every wave is past its last read of the stages
+        float* red = reinterpret_cast<float*>(smem);           // [16 row groups][128 columns]
+        float* rp = red + cs_rg * 128 + 8 * cs_c8;
+        rp[0] = cs0; rp[1] = cs1; rp[2] = cs2; rp[3] = cs3; rp[4] = cs4; rp[5] = cs5; rp[6] = cs6; rp[7] = cs7;
+        __syncthreads();
+        if (tid < WM) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sum += red[g * 128 + tid];
+            if (m0 + tid < a.N) (a.colsum + (size_t)bz * a.slab_stride)[m0 + tid] = sum;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + li;
+        if (n >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mb = m0 + wm + 32 * i + 4 * lh;
+            if (m0 + wm + 32 * i + 31 < a.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) C[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * a.K + n] = acc[i][j][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < a.N) C[(size_t)m * a.K + n] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_pair16_kernel(WgradArgs a0, WgradArgs a1, int n0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool f = (int)blockIdx.x < n0;
+    WgradArgs a;
+    a.dy = f ? a0.dy : a1.dy; a.x = f ? a0.x : a1.x; a.out = f ? a0.out : a1.out; a.colsum = f ? a0.colsum : a1.colsum;
+    a.R = a0.R; a.N = a0.N; a.K = f ? a0.K : a1.K; a.ldy = a0.ldy; a.ldx = f ? a0.ldx : a1.ldx;
+    a.nx = f ? a0.nx : a1.nx; a.ny = a0.ny; a.nz = a0.nz; a.tiles_per_split = a0.tiles_per_split;
+    a.slab_stride = f ? a0.slab_stride : a1.slab_stride;
+    a.remap_from = f ? a0.remap_from : a1.remap_from; a.remap_add = f ? a0.remap_add : a1.remap_add;
+    wgrad16_body(a, f ? (int)blockIdx.x : (int)blockIdx.x - n0, smem);
+}
+
 // ---- The all-bf16 form on 256 x 256 tiles (round 3): the GRU's two weight gradients on the step's tail.
 // The 128 x 128 kernel above is bound by its k-loop's per-stage latency (header): a wave has 8 MFMAs (256 pipe cycles) per
 // 32-row stage between two waits and a barrier.  Here a workgroup of 4 waves owns 256 dY columns x 256 X columns, a wave
@@ -467,11 +626,11 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const int bid
     float* C = a.out + (size_t)bz * a.slab_stride;
     if (do_cs) {
         // sum the eight row groups' partial column sums through LDS (the stages are free: every wave is past its last read)
-        __builtin_amdgcn_s_barrier();
+        __syncthreads();
         float* red = reinterpret_cast<float*>(smem);           // [8 row groups][256 columns]
         float* rp = red + cs_rg * 256 + 8 * cs_c8;
         rp[0] = cs0; rp[1] = cs1; rp[2] = cs2; rp[3] = cs3; rp[4] = cs4; rp[5] = cs5; rp[6] = cs6; rp[7] = cs7;
-        __builtin_amdgcn_s_barrier();
+        __syncthreads();
         float sum = 0.f;
 #pragma unroll
         for (int g = 0; g < 8; ++g) sum += red[g * 256 + tid];
@@ -753,6 +912,33 @@ extern "C" int svae_f32_to_bf16(const float* src, void* dst, long long n, void* 
     long long nb = (n / 8 + 255) / 256;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n / 8);
+    SV_LAUNCH_CHECK();
+    return 0;
+}
+
+// svae_wgrad_pair_bf16dy with BOTH X operands as bf16 elements (x0: the bf16 copy of the previous hidden states), on the
+// hand-waited all-bf16 kernel (wgrad16_body): same workgroups, same slabs; the weight gradients are bit-identical to
+// svae_wgrad_cols_bf16dy_bf16x's, the bias gradients (column sums) agree to summation order.
+extern "C" int svae_wgrad_pair_bf16(const void* dy, int R, int N, int ldy, int nsplit,
+                                    const void* x0, int K0, int ldx0, float* out0, float* colsum0, long long stride0,
+                                    int remap_from0, int remap_add0,
+                                    const void* x1, int K1, int ldx1, float* out1, float* colsum1, long long stride1,
+                                    int remap_from1, int remap_add1, void* stream) {
+    SV_CHECK_ARG((ldy % 8) == 0 && (ldx0 % 8) == 0 && (ldx1 % 8) == 0 && (remap_from0 % 8) == 0 && (remap_add0 % 8) == 0 &&
+                     (remap_from1 % 8) == 0 && (remap_add1 % 8) == 0,
+                 "svae_wgrad_pair_bf16: bad alignment");
+    WgradArgs a0, a1;
+    int g0, g1;
+    if (int rc = wgrad_args(dy, (const float*)x0, out0, colsum0, R, N, K0, ldy, ldx0, nsplit, stride0, remap_from0, remap_add0, a0, g0)) return rc;
+    if (int rc = wgrad_args(dy, (const float*)x1, out1, colsum1, R, N, K1, ldy, ldx1, nsplit, stride1, remap_from1, remap_add1, a1, g1)) return rc;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_pair16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE_BYTES);
+        if (e != hipSuccess) return svae_fail((int)e, "svae_wgrad_pair_bf16: LDS attribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int n0 = 8 * ((nsplit + 7) / 8) * g0, n1 = 8 * ((nsplit + 7) / 8) * g1;
+    hipLaunchKernelGGL(wgrad_pair16_kernel, dim3(n0 + n1), dim3(256), NST * STAGE_BYTES, (hipStream_t)stream, a0, a1, n0);
     SV_LAUNCH_CHECK();
     return 0;
 }

@@ -126,6 +126,10 @@ class SVAEEngine:
         # LDS, one wave per SIMD) and wait for the CUs the weight-gradient sweep holds, where the 128 x 128 kernel's
         # fit in beside the sweep's.  Off; kept as a library entry point with its test (tests/test_gpu_wgrad.py).
         self.wgrad_big = _opt("SVAE_WGRAD_BIG", "0") == "1"
+        # The GRU's two weight gradients on the all-bf16 128 x 128 kernel with hand-counted waits (svae_wgrad_pair_bf16;
+        # its recurrent-weight job reads a bf16 copy of the previous hidden states made beside the BPTT): 31 us against 48
+        # alone, weight gradients bit-identical
+        self.wgrad16 = _opt("SVAE_WGRAD16", "1") == "1"
         self.nsplit_big = 40                                       # (6 output tiles x 40 row splits = 240 workgroups)
         self.slabs = torch.zeros(max(self.nsplit, self.nsplit_big) * (G * E + G), **f32)        # largest split-K output: dW_ih
         self.slabs_side = torch.zeros(self.nsplit * (DP * HP + DP), **f32)  # side-stream weight gradients
@@ -1169,9 +1173,9 @@ class SVAEEngine:
                     proj_dw(w["pslabs_side"])
                     self._bucket(0)
                 self._stamp("side dense weight gradients may start")
-                if self._big_wgrads(dg16):
-                    # the bf16 copy of the previous hidden states for the 256-tile weight-gradient kernel: here, beside
-                    # the BPTT, where this stream has time (5 us; the kernel rounds to bf16 anyway: same products)
+                if self._bf16_wgrads(dg16):
+                    # the bf16 copy of the previous hidden states for the all-bf16 weight-gradient kernels: here, beside
+                    # the BPTT, where this stream has time (4 us; the kernels round to bf16 anyway: same products)
                     _lib.call("svae_f32_to_bf16", w["hprev"].data_ptr(), w["hprev16"].data_ptr(), R * HP, _stream())
                 decoder_side_wgrads(self.slabs_side)
                 self._stamp("side dense weight gradients done")
@@ -1220,7 +1224,19 @@ class SVAEEngine:
             # kernel trace shows the caller's queue busy 898 of a step's 971 us -- it is the critical path, and by the
             # end of the BPTT the side stream has been idle for ~70 us.)
             ns = max(1, min(self.nsplit, (R + 127) // 128))
-            if self._big_wgrads(dg16) and side is not None and not tb:
+            if self._bf16_wgrads(dg16) and not self.wgrad_big and side is not None and not tb and ns > 1:
+                o_hh = self._gbase + 4 * self.layout.offset("gru.weight_hh_l0")
+                o_ih = self._gbase + 4 * self.layout.offset("gru.weight_ih_l0")
+                s_hh, s_ih = self.slabs_hh.data_ptr(), self.slabs.data_ptr()
+                st_hh, st_ih = G * HP + G, G * E + G
+                ev = self._tic("wgrad")
+                _lib.call("svae_wgrad_pair_bf16", dgi.data_ptr(), R, G, ldg, ns,
+                          w["hprev16"].data_ptr(), HP, HP, s_hh, s_hh + 4 * G * HP, st_hh, hh_remap[0], hh_remap[1],
+                          w["emb16"].data_ptr(), E, E, s_ih, s_ih + 4 * G * E, st_ih, (G + 7) // 8 * 8, 0, _stream())
+                _lib.call("svae_reduce_slabs_pair", s_hh, o_hh, st_hh, st_hh, s_ih, o_ih, st_ih, st_ih, ns, _stream())
+                self._toc("wgrad", ev)
+                return
+            if self._bf16_wgrads(dg16) and self.wgrad_big and side is not None and not tb:
                 # both on 256 x 256 tiles, all operands bf16 (svae_wgrad_pair_big: 36 us against 48 alone at 21.8k rows)
                 nb = max(2, min(self.nsplit_big, (R + 255) // 256))
                 o_hh = self._gbase + 4 * self.layout.offset("gru.weight_hh_l0")
@@ -1297,11 +1313,12 @@ class SVAEEngine:
         self._loss_deferred = False
         self._bucket(1)      # dense layers (side stream) + GRU (this stream): behind the join
 
-    def _big_wgrads(self, dg16):
-        """The GRU's weight gradients take the 256 x 256-tile kernel: bf16 gradient array, bf16 embedding rows, the
-        overlapped step (the bf16 copy of the hidden states is made on the side stream)."""
-        return bool(self.wgrad_big and dg16 and self._emb16_live and self.fused and self.overlap and self.wgrad_pair
-                    and self.gru_wgrad_side and not self.bptt_split)
+    def _bf16_wgrads(self, dg16):
+        """The GRU's weight gradients take an all-bf16 kernel (svae_wgrad_pair_bf16, or svae_wgrad_pair_big on request):
+        bf16 gradient array, bf16 embedding rows, the overlapped step (the bf16 copy of the hidden states is made on the
+        side stream beside the BPTT)."""
+        return bool((self.wgrad16 or self.wgrad_big) and dg16 and self._emb16_live and self.fused and self.overlap
+                    and self.wgrad_pair and self.gru_wgrad_side and not self.bptt_split)
 
     def _tail_two_ranges(self, plan, cur, side, late_done, dg, ldg, rb, hh_remap):
         """Tail of backward with a two-range BPTT (bf16 gradient array dg [R][ldg]): rows >= rb were final at

@@ -169,12 +169,14 @@ def test_gru_gradient_array_forms_agree():
     users = synth.make_users(B, I, 3.6, 0.6, 120, seed=11)
     plan = S.build_plan(users, 4, user_keys=np.arange(B), device="cuda", total_items=I)
     grads = []
-    for merged, bf16, big in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+    for merged, bf16, big, w16 in ((False, False, False, False), (True, False, False, False), (True, True, False, False),
+                                   (True, True, True, False), (True, True, False, True)):
         eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
         torch.manual_seed(1)
         eng.load_state_dict({n: torch.randn(s) * 0.1 for n, s in eng.layout.ref_shapes.items()})
         eng.merged_dg, eng.dg_bf16 = merged, bf16
         eng.wgrad_big = big        # (the 256 x 256-tile kernel sums in another order: compared separately below)
+        eng.wgrad16 = w16          # (the production kernel of the GRU's weight gradients: hand-counted waits, bf16 hidden states)
         eng.forward(plan, 0.05, seed=3, step=1)
         eng.backward()
         torch.cuda.synchronize()
@@ -191,6 +193,13 @@ def test_gru_gradient_array_forms_agree():
         # the same bf16 products, another summation order (tiles, split count)
         d = float((grads[2][k] - grads[3][k]).abs().max())
         assert d <= 3e-6 * float(grads[2][k].abs().max()), ("256-tile weight gradients", k, d)
+        # the production form (engine.wgrad16): the same tiles, stages and MFMA order on a bf16 copy of the hidden states
+        # -- every weight gradient bit-identical; the two GRU bias gradients (column sums) in another summation order
+        if k in ("gru.bias_ih_l0", "gru.bias_hh_l0"):
+            d = float((grads[2][k] - grads[4][k]).abs().max())
+            assert d <= 3e-6 * float(grads[2][k].abs().max()), ("hand-waited kernel, bias", k, d)
+        else:
+            assert torch.equal(grads[2][k], grads[4][k]), ("hand-waited kernel", k)
 
 
 def test_fused_operand_copies_equal_the_two_kernel_path():
@@ -255,6 +264,7 @@ def test_step_order_options_leave_the_step_bit_identical():
         eng.head_fused, eng.mlp2_side, eng.emb16 = head, mlp2, e16
         eng.wgrad_pair = pair      # the two GRU weight gradients in one launch (svae_wgrad_pair_bf16dy) or in two
         eng.wgrad_big = False      # (the 256 x 256-tile kernel sums in another order: test_gru_gradient_array_forms_agree)
+        eng.wgrad16 = False        # (the hand-waited kernel sums the two GRU BIAS gradients in another order: same test)
         eng.prepare(plan)
         losses = []
         for s in range(3):
@@ -543,3 +553,33 @@ def test_first_time_range_keeps_half_the_chip_at_large_batches():
     big = S.SVAEEngine(200000, device="cuda", prec=S.PREC_BF16)
     assert eng._dw_workgroups(20000, eng._ncu) == min(eng._ncu, eng.dw_wgs)
     assert big._dw_workgroups(20000, big._ncu) == big._ncu - 32 and big._range1_cus(types.SimpleNamespace(B=256)) == big._ncu
+
+
+def test_training_is_bit_reproducible_over_many_steps():
+    """160 training steps over 16 ML-20M-shaped plans, three times from the same state: parameters and optimizer state end
+    BIT-IDENTICAL.  Every reduction in the step has a fixed order (slabs, no atomics), so any difference is a missing
+    dependency between streams or inside a kernel -- round 3 found one this way: an LDS reduction behind a bare s_barrier
+    (no wait for the LDS writes in front of it) made two bias gradients differ in the last bits every few dozen steps."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    I, B = 20000, 256
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    users = synth.make_users(4096, I, mu, sigma, lmax, seed=98765)
+    batches = synth.bucketed_batches([len(u) for u in users], B, np.random.default_rng(98765))[:16]
+    plans = [S.build_plan([users[i] for i in idx], 4, user_keys=idx, device="cuda", total_items=I) for idx in batches]
+    outs = []
+    for run in range(3):
+        eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+        _init(eng, 7)
+        eng.reserve(max(p.R for p in plans))
+        for p in plans:
+            eng.prepare(p)
+        with torch.cuda.stream(eng.training_stream()):
+            for i in range(160):
+                eng.train_step(plans[i % 16], 0.05, seed=3)
+        torch.cuda.synchronize()
+        outs.append((eng.params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone()))
+        assert bool(torch.isfinite(outs[-1][0]).all())
+    for run in (1, 2):
+        for a, b, what in zip(outs[0], outs[run], ("parameters", "first moments", "second moments")):
+            assert torch.equal(a, b), (run, what, int((a != b).sum()))

@@ -167,3 +167,32 @@ def test_wgrad_pair_on_256_tiles_equals_the_128_tile_kernels(R, ns):
     cols = torch.cat([torch.arange(448), torch.arange(448, 672) + 224]).cuda()
     ref0 = dyf[:, cols].t() @ x0b[:R].double()
     assert float((b0[: N * K0].reshape(N, K0) - ref0).abs().max()) <= 1e-5 * float(ref0.abs().max())
+
+
+@pytest.mark.parametrize("R,ns", [(333, 3), (4099, 32), (21814, 32)])
+def test_hand_waited_bf16_pair_equals_the_builtin_read_kernels(R, ns):
+    """svae_wgrad_pair_bf16 (inline-asm LDS reads, hand-counted waits) against svae_wgrad_cols_bf16dy_bf16x on the same
+    bf16 operands: the same tiles, stages and MFMA order -- weight gradients BIT-IDENTICAL; the bias gradients (column
+    sums, summed in another order) to 2e-6 of their scale."""
+    N, ldy, K0, K1 = 672, 896, 224, 256
+    g = torch.Generator(device="cuda").manual_seed(R + 1)
+    dy = (torch.randn(R + 3, ldy, device="cuda", generator=g) * 0.1).bfloat16()
+    x0 = torch.randn(R + 3, K0, device="cuda", generator=g).bfloat16()
+    x1 = torch.randn(R + 3, K1, device="cuda", generator=g).bfloat16()
+    r0, r1 = (448, 224), (672, 0)
+    a = _run("svae_wgrad_cols_bf16dy_bf16x", dy, x0, R, N, K0, ldy, K0, ns, r0)
+    b = _run("svae_wgrad_cols_bf16dy_bf16x", dy, x1, R, N, K1, ldy, K1, ns, r1)
+    st0, st1 = N * K0 + N, N * K1 + N
+    s0 = torch.full((ns * st0,), float("nan"), device="cuda")
+    s1 = torch.full((ns * st1,), float("nan"), device="cuda")
+    o0, o1 = torch.empty(st0, device="cuda"), torch.empty(st1, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("svae_wgrad_pair_bf16", dy.data_ptr(), R, N, ldy, ns,
+              x0.data_ptr(), K0, K0, s0.data_ptr(), s0.data_ptr() + 4 * N * K0, st0, r0[0], r0[1],
+              x1.data_ptr(), K1, K1, s1.data_ptr(), s1.data_ptr() + 4 * N * K1, st1, r1[0], r1[1], st)
+    _lib.call("svae_reduce_slabs_pair", s0.data_ptr(), o0.data_ptr(), st0, st0, s1.data_ptr(), o1.data_ptr(), st1, st1, ns, st)
+    torch.cuda.synchronize()
+    o0, o1 = o0.cpu().numpy(), o1.cpu().numpy()
+    assert np.array_equal(o0[: N * K0].reshape(N, K0), a[0]) and np.array_equal(o1[: N * K1].reshape(N, K1), b[0])
+    for got, ref in ((o0[N * K0:], a[1]), (o1[N * K1:], b[1])):
+        assert np.all(np.isfinite(got)) and float(np.abs(got - ref).max()) <= 2e-6 * float(np.abs(ref).max())

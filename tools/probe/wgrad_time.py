@@ -41,3 +41,5 @@ for nsb in (24, 32, 40, 48):
           emb16.data_ptr(), E, E, a_ih, a_ih + 4 * G * E, G * E + G, 672, 0, st)))
 print("fp32 -> bf16 copy of hprev : %.1f us" % run("svae_f32_to_bf16", hprev.data_ptr(), hprev16.data_ptr(), R * HP, st))
 print("reduce pair (40 splits)    : %.1f us" % run("svae_reduce_slabs_pair", a_hh, s_hh.data_ptr(), G * HP + G, G * HP + G, a_ih, s_ih.data_ptr(), G * E + G, G * E + G, 40, st))
+print("pair, 128 tiles, all bf16, hand-counted waits : %.1f us" % run("svae_wgrad_pair_bf16", dg.data_ptr(), R, G, 896, 32, hprev16.data_ptr(), HP, HP, a_hh, a_hh + 4 * G * HP, G * HP + G, 448, 224,
+      emb16.data_ptr(), E, E, a_ih, a_ih + 4 * G * E, G * E + G, 672, 0, st))
