@@ -1185,7 +1185,9 @@ class SVAEEngine:
                     # side stream's join point, the caller's stream waiting for it only at the end of train_step, so
                     # that it no longer sits in front of the GRU weight gradients -- measured 0.7 % SLOWER, 0.8728 vs
                     # 0.8666 ms per step over three alternating pairs (tools/ab_env.sh): a kernel trace, where this
-                    # kernel shows as 8 - 25 us on the chain into the optimizer, is no guide to the untraced step.)
+                    # kernel shows as 8 - 25 us on the chain into the optimizer, is no guide to the untraced step.
+                    #  Round 3, on the caller's stream behind the scatter-add, where that stream waits ~20 us for this one
+                    #  anyway: 0.6 % slower again, 0.8434 vs 0.8386 ms, two alternating pairs.)
                     _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(),
                               plan.w_nll.data_ptr(), plan.w_kl.data_ptr(), float(anneal), R,
                               self.loss_out.data_ptr(), _stream())
