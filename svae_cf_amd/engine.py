@@ -1296,7 +1296,10 @@ class SVAEEngine:
             self._stamp("q1 dL/demb + scatter-add done")
             _lib.stream_wait(side, bptt_done)
             with _Launch(side, self._torch_ctx()):
-                gru_wgrads()          # (one of the two here and one on the caller's stream: no better, 0.922 vs 0.918)
+                gru_wgrads()          # (one of the two here and one on the caller's stream: no better, 0.922 vs 0.918;
+                                      #  round 3, both on a THIRD stream so that they do not queue behind the dense-layer
+                                      #  gradients and the loss reduce, which end ~20 us after the BPTT: 0.8278 vs 0.8285,
+                                      #  nothing -- the tail is short of CUs, not of ordering freedom)
                 self._stamp("side GRU weight gradients done")
         elif self.tail_embedding_first:
             embedding_grad()
