@@ -201,7 +201,10 @@ class SVAEEngine:
         self.dw_wgs = int(_opt("SVAE_DW_WGS", "158"))
         self.range1_cus = int(_opt("SVAE_RANGE1_CUS", "0"))           # tuning: workgroups of the first range's forward sweep
         self.dw_wgs_exact = _opt("SVAE_DW_WGS_EXACT", "0") == "1"     # tuning: dw_wgs as given, whatever the shape
-        self.dw_early = _opt("SVAE_DW_EARLY", "1") == "1"      # the weight-gradient sweep starts behind the forward sweep
+        # the weight-gradient sweep starts behind the forward sweep (not behind the MLP backward): from ~4 000 items on --
+        # ML-20M shape with 6 000 / 10 000 / 14 000 / 20 000 items: -0.2 / -1.2 / -0.5 / -1.2 %; at the ML-1M shape (3 483
+        # items) the sweep is 70 us and starting it beside the MLP backward costs 0.9 % (0.7344 against 0.7281 ms)
+        self.dw_early = _opt("SVAE_DW_EARLY", "1" if self.I >= 4096 else "0") == "1"
         self.head_fused = _opt("SVAE_HEAD_FUSED", "1") == "1"
         # bf16 mode: the gathered embedding rows are kept as bf16 (their two consumers -- the input-gate GEMM and the
         # input-weight gradient -- round them to bf16 anyway: bit-identical) -- half the bytes written by the gather,
