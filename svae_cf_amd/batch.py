@@ -65,18 +65,24 @@ class BatchPlan:
         return self._row_of
 
 
-def choose_time_split(row_off, us_per_step=2.4, us_launch=15.0, us_chain=40.0, us_per_row=0.011, cu_share=0.75):
+def choose_time_split(row_off, total_items=0, us_per_step=2.4, us_launch=15.0, us_chain=40.0, us_per_row=None, cu_share=0.75):
     """Where to cut the forward in two time ranges (engine.forward, fused mode): the GRU recurrence is a chain of
     Tmax latency-bound steps on a quarter of the CUs, the decoder side of a row (MLP chain + projection sweep) is
     throughput-bound and only needs the row's h_t -- so the rows of timesteps < t1 go through the decoder side
     while the recurrence runs steps >= t1.  Rows are time-major, so they are the first row_off[t1] rows; the cut
     is rounded down to a multiple of 64 rows (the rows in between ride with the second range).
     Cost model (measured on MI355X, ML-20M shape): a recurrence launch = 15 us + 2.4 us per step; the decoder side
-    of r rows = 40 us + 11 us per 1000 rows, 1/0.75 of that while the recurrence holds a quarter of the CUs.
+    of r rows = 40 us + 11 us per 1000 rows (at 20 000 items; by catalogue size, below), 1/0.75 of that while the
+    recurrence holds a quarter of the CUs.
     (Round 2, faster sweeps: the constants re-checked by moving each 20-30 % either way -- every variant 0.5-2 % slower;
     again with the second range's MLP chain behind its recurrence on the side stream: +-25 / +50 us on the second
     recurrence's side of the model, 0.3-1 % slower.)
     Returns (t1, r1), or (0, 0) when no cut beats the unsplit forward by 5 %."""
+    if us_per_row is None:
+        # the decoder side's cost per row grows with the catalogue (the sweep's share of it): 11 us per 1000 rows at 20 000
+        # items (rounds 1-2), 2.5 at the ML-1M shape's 3 483 (round 3: 0.011 -> 0.7306 ms per step, 0.006 -> 0.7236,
+        # 0.003 -> 0.7208, 0.002 -> 0.7188, 0.001 and below -> no cut, 0.7395); linear in between and beyond
+        us_per_row = 0.0007 + 5.15e-7 * float(total_items) if total_items and total_items > 0 else 0.011
     row_off = np.asarray(row_off, dtype=np.int64)
     Tmax, R = len(row_off) - 1, int(row_off[-1])
     best, arg = us_launch + us_per_step * Tmax + us_chain + us_per_row * R, (0, 0)
@@ -194,7 +200,7 @@ def build_plan(users, next_k, user_keys=None, device=None, pin=False, total_item
     p.B, p.R, p.Tmax, p.K = B, R, Tmax, K
     p.order = order
     p.lengths = T
-    p.split_t, p.split_r = choose_time_split(row_off)
+    p.split_t, p.split_r = choose_time_split(row_off, total_items or 0)
     p.nseg = int(len(seg_item))
     p.nseg_long = nseg_long
     p._row_off_host = row_off

@@ -63,8 +63,9 @@ void order_by_count_desc(const int64_t* cnt, int64_t n, int64_t max_cnt, std::ve
 }
 
 // batch.py:choose_time_split (same constants, same order of the floating-point operations)
-void choose_time_split(const int32_t* row_off, int Tmax, int* t_out, int* r_out) {
-    const double us_per_step = 2.4, us_launch = 15.0, us_chain = 40.0, us_per_row = 0.011, cu_share = 0.75;
+void choose_time_split(const int32_t* row_off, int Tmax, int total_items, int* t_out, int* r_out) {
+    const double us_per_step = 2.4, us_launch = 15.0, us_chain = 40.0, cu_share = 0.75;
+    const double us_per_row = total_items > 0 ? 0.0007 + 5.15e-7 * (double)total_items : 0.011;
     const int64_t R = row_off[Tmax];
     double best = us_launch + us_per_step * Tmax + us_chain + us_per_row * (double)R;
     const double base = best;
@@ -316,7 +317,7 @@ extern "C" void* svae_plan_create(const int* items, const long long* user_off, c
     p.info.Tmax = Tmax;
     p.info.K = K;
     p.info.total_items = total_items;
-    choose_time_split(p.row_off.data(), Tmax, &p.info.split_t, &p.info.split_r);
+    choose_time_split(p.row_off.data(), Tmax, total_items, &p.info.split_t, &p.info.split_r);
     p.info.total_bytes = layout(p, nullptr, p.info.off);
     *info = p.info;
     return pp;

@@ -9,7 +9,7 @@ import sys
 d = json.load(open(sys.argv[1]))
 e = json.load(open(sys.argv[2]))
 y = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
-modes = [m for m in ("bf16", "split", "split@6", "bf16@6") if m in d["plateau"]]
+modes = [m for m in ("bf16", "split", "split@6", "bf16@6", "split@7", "bf16@7", "split@8", "bf16@8") if m in d["plateau"]]
 P = dict(d["plateau"])
 if y is not None:
     P["split, generic fp32 GRU kernels"] = y["plateau"]["split"]
@@ -22,7 +22,7 @@ def df(a, b, k):
 
 L = []
 L.append("# r03a -- training in the timed mode (bf16) beside the fp32-class mode (split), and beside another noise seed\n")
-L.append("`tools/convergence.py --train-users 5120 --val-users 1536 --steps 6400 --modes bf16,split,split@6,bf16@6` on one "
+L.append("`tools/convergence.py --train-users 5120 --val-users 1536 --steps 6400 --modes bf16,split,split@6,bf16@6[,bf16@7,split@7,bf16@8,split@8]` on one "
          "MI355X (ML-1M-shaped synthetic: 3 483 items; batches of 64 users = 80 optimizer steps per epoch; Adam lr 1e-3 + L2 "
          "5e-3 as nb:1260-1263; the reference's KL schedule per user; validation = `evaluate()` on 1 536 held-out users, "
          "80/20 split, after every epoch). Same initial parameters, same batches, same Philox noise in bf16 and split; `@6` = "
@@ -35,7 +35,8 @@ L.append("| run | val loss | NDCG@10 | Rec@10 | NDCG@100 | Rec@100 |\n|---|---|-
 for m in list(modes) + ([k for k in P if k not in modes]):
     L.append("| %s | " % m + " | ".join("%.3f +- %.3f" % (P[m][k]["mean"], P[m][k]["std"]) for k in KEYS) + " |")
 L.append("\n| difference of plateau means | val loss (rel.) | NDCG@100 | Rec@100 |\n|---|---|---|---|")
-rows = [("bf16", "split", "bf16 - split, seed 5"), ("bf16@6", "split@6", "bf16 - split, seed 6"),
+rows = [("bf16", "split", "bf16 - split, seed 5"), ("bf16@6", "split@6", "bf16 - split, seed 6")] + \
+       [("bf16@%d" % s_, "split@%d" % s_, "bf16 - split, seed %d" % s_) for s_ in (7, 8) if "bf16@%d" % s_ in d["plateau"]] + [
         ("split@6", "split", "split: seed 6 - seed 5 (one fp32-class implementation, two noise seeds)"),
         ("bf16@6", "bf16", "bf16: seed 6 - seed 5")]
 if y is not None:
@@ -45,11 +46,12 @@ if y is not None:
 for a, b, n in rows:
     L.append("| %s | %.1e | %+.3f | %+.3f |" % (n, abs(df(a, b, "loss")) / P[b]["loss"]["mean"], df(a, b, "NDCG@100"),
                                                df(a, b, "Rec@100")))
-avg = {k: 0.5 * (df("bf16", "split", k) + df("bf16@6", "split@6", k)) for k in ("NDCG@100", "Rec@100")}
-L.append("| **bf16 - split, average of the two seeds** | | **%+.3f** | **%+.3f** |" % (avg["NDCG@100"], avg["Rec@100"]))
+pairs_ = [("bf16", "split"), ("bf16@6", "split@6")] + [("bf16@%d" % s_, "split@%d" % s_) for s_ in (7, 8) if "bf16@%d" % s_ in d["plateau"]]
+avg = {k: sum(df(a_, b_, k) for a_, b_ in pairs_) / len(pairs_) for k in ("NDCG@100", "Rec@100")}
+L.append("| **bf16 - split, mean over the %d seeds** | | **%+.3f** | **%+.3f** |" % (len(pairs_), avg["NDCG@100"], avg["Rec@100"]))
 c = d["comparison"]
 L.append("\nThe bf16 mode reaches the plateau of the fp32-class mode: per seed its offset is below one point (north_star's "
-         "0.5 is met on the average of the two seeds: %+.2f NDCG@100, %+.2f Rec@100) and of the size of the offset between "
+         "0.5 is met on the mean over the seeds: %+.2f NDCG@100, %+.2f Rec@100) and of the size of the offset between "
          "two noise seeds of the fp32-class mode itself. Single evaluations move by +-0.4-0.8 from epoch to epoch within ONE "
          "run (the standard deviations above), so single evaluations of two runs differ by up to %.1f NDCG@100 / %.1f Rec@100 "
          "(bf16 vs split) and %.1f / %.1f (two seeds of split, during the steep phase around step 1 500): a 0.5 gate on "
