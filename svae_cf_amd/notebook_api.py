@@ -533,11 +533,14 @@ def _metrics_from_ranks(rank, n_held, Ks=(10, 100)):
     if (n_held == 0).any():
         raise ZeroDivisionError("a user without held-out items (the reference divides by zero there too, nb:646)")
     owner = np.repeat(np.arange(U), n_held)
+    listed = rank >= 0                       # only items in the ranking add anything (x + 0.0 == x: same sums without the rest)
+    owner, rank = owner[listed], rank[listed]
     out = {}
     for k in Ks:
-        hit = (rank >= 0) & (rank < k)
-        hits = np.bincount(owner, weights=hit.astype(np.float64), minlength=U)
-        dcg = np.bincount(owner, weights=np.where(hit, _INV_LOG2[np.maximum(rank, 0) + 2], 0.0), minlength=U)
+        hit = rank < k
+        own_k = owner[hit]
+        hits = np.bincount(own_k, minlength=U).astype(np.float64)
+        dcg = np.bincount(own_k, weights=_INV_LOG2[rank[hit] + 2], minlength=U)
         best = _IDEAL[np.minimum(n_held, k)]
         out["NDCG@%d" % k] = dcg / best
         out["Rec@%d" % k] = hits / n_held.astype(np.float64)
@@ -596,7 +599,8 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
         hoff = np.zeros(len(pairs) + 1, dtype=np.int64)
         np.cumsum(hcnt, out=hoff[1:])
         hflat = np.fromiter((i for _, h in pairs for i in h), dtype=np.int32, count=int(hoff[-1]))
-        cache = (ckey, reader.data, UserCSR([f for f, _ in pairs]), hflat, hoff, pairs, batch)
+        ulen = hcnt + np.fromiter((len(f) for f, _ in pairs), dtype=np.int64, count=len(pairs))   # nb:653's map key
+        cache = (ckey, reader.data, UserCSR([f for f, _ in pairs]), hflat, hoff, pairs, batch, ulen)
         try:
             reader._svae_eval_cache = cache
         except AttributeError:
@@ -632,13 +636,23 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
     t_loop = time.perf_counter()
     rank_all = rank_dev.cpu().numpy()
     t_sync = time.perf_counter()
-    for s0 in my_starts:
-        n = min(batch_size, len(pairs) - s0)
-        r = rank_all[hoff[s0]:hoff[s0 + n]]
-        if len(r) and r.min() < -1:
-            raise RuntimeError("evaluate: a scored user's held-out ranks were not written (user keys of the plan?)")
-        per = _metrics_from_ranks(r, np.diff(hoff[s0:s0 + n + 1]), Ks)
-        mine[s0] = np.stack([per[nm] for nm in names], axis=1)
+    # one pass of the metric arithmetic over all of this rank's users (every user's value depends on that user's
+    # ranks alone, so the grouping into batches does not show in the result), then cut back into the batches
+    spans = [(s0, min(batch_size, len(pairs) - s0)) for s0 in my_starts]
+    if world == 1:
+        r_mine, held_mine = rank_all[:int(hoff[-1])], np.diff(hoff)
+    else:
+        r_mine = np.concatenate([rank_all[hoff[s0]:hoff[s0 + n]] for s0, n in spans] or [np.zeros(0, np.int32)])
+        held_mine = np.concatenate([np.diff(hoff[s0:s0 + n + 1]) for s0, n in spans] or [np.zeros(0, np.int64)])
+    if len(r_mine) and r_mine.min() < -1:
+        raise RuntimeError("evaluate: a scored user's held-out ranks were not written (user keys of the plan?)")
+    if spans:
+        per = _metrics_from_ranks(r_mine, held_mine, Ks)
+        rows_mine = np.stack([per[nm] for nm in names], axis=1)
+        at = 0
+        for s0, n in spans:
+            mine[s0] = rows_mine[at:at + n]
+            at += n
     losses = loss_dev.cpu().numpy() if my_starts else np.zeros(0, dtype=np.float32)
     # (diagnostic: host time of the scoring loop, of it blocked on plans, then the wait for the GPU, then the metrics)
     evaluate.last_timing = dict(loop_s=t_loop - t_begin, plans_wait_s=plans.wait_s, drain_s=t_sync - t_loop,
@@ -654,14 +668,18 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
             mine.update(p_)
     loss_sum, sums, len_map = 0.0, dict.fromkeys(names, 0.0), {}
     for s in starts:                                           # the single-process order of additions
-        chunk = pairs[s:s + batch_size]
-        lsum, rows = mine[s]
-        loss_sum += lsum
-        for j, n in enumerate(names):
-            sums[n] = _running_sum(sums[n], rows[:, j])
-        j100 = names.index("NDCG@100")
-        for u, (f, h) in enumerate(chunk):
-            len_map.setdefault(int(len(h)) + (len(f) - 1) + 1, []).append(float(rows[u, j100]))
+        loss_sum += mine[s][0]
+    rows = np.concatenate([mine[s][1] for s in starts]) if starts else np.zeros((0, len(names)))
+    for j, n in enumerate(names):                              # one left-to-right sum over the users in their order
+        sums[n] = _running_sum(0.0, rows[:, j])
+    # len_to_ndcg_at_100_map (nb:653): key = held-out + fold-in items of the user (len(h) + (len(f) - 1) + 1), the
+    # users' NDCG@100 in user order under each key, keys in order of first appearance
+    ulen, ndcg100 = cache[7], rows[:, names.index("NDCG@100")]
+    order = np.argsort(ulen, kind="stable")
+    keys, first, count = np.unique(ulen, return_index=True, return_counts=True)
+    begin = np.concatenate(([0], np.cumsum(count)))
+    for g in np.argsort(first):
+        len_map[int(keys[g])] = ndcg100[order[begin[g]:begin[g + 1]]].tolist()
     total_users = float(len(pairs))
     metrics = {"loss": round(float(loss_sum) / float(batch), 4)}
     for n in names:
