@@ -42,13 +42,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void kd(unsigned long long* out, flo
             for (int i = 0; i < 10; ++i) Z[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, Z[i >> 1], 0, 0, 0);
         }
         if (NOWAIT) {}
-        else if (npc == 3 && DEPTH == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (npc == 2 && DEPTH == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (npc == 3 && DEPTH == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (npc == 2 && DEPTH == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (npc == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else if (npc == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (npc == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else {      // all but the youngest DEPTH - 2 tiles' pieces of this wave have landed
+            const int n = (DEPTH - 2) * npc;
+            if (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (MODE == 4) __builtin_amdgcn_s_barrier();
         sj = sj == 6 ? 0 : sj + 1;
     }
@@ -214,6 +219,13 @@ int main() {
         rund<4, 3, 0, 6>("sweep + LDS-DMA 20K depth 6 + barrier", blocks);
         rund<4, 3, 0, 4>("sweep + LDS-DMA 20K depth 4 + barrier", blocks);
         rund<4, 2, 0, 4>("sweep + LDS-DMA 16K depth 4 + barrier", blocks);
+        rund<4, 5, 0, 3>("20K, waves 4-7 three, depth 3", blocks);
+        rund<4, 5, 0, 4>("20K, waves 4-7 three, depth 4", blocks);
+        rund<4, 5, 0, 6>("20K, waves 4-7 three, depth 6", blocks);
+        rund<4, 4, 0, 3>("24K (3 each), depth 3", blocks);
+        rund<4, 4, 0, 4>("24K (3 each), depth 4", blocks);
+        rund<4, 2, 0, 3>("16K, depth 3", blocks);
+        rund<4, 5, 1>("20K, waves 4-7 three, nowait", blocks);
         rund<4, 3, 1>("sweep + LDS-DMA 20K nowait + barrier", blocks);
         rund<4, 1, 1>("sweep + LDS-DMA 8K nowait + barrier", blocks);
     }
