@@ -371,6 +371,10 @@ __device__ __forceinline__ unsigned topk_key(float v) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+__device__ __forceinline__ float topk_unkey(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
 // K rounds of arg-max over work[] (destroys it); writes entries k0.. of the result
 __device__ void topk_rounds(float* w, int I, int k0, int K, int* out_idx, float* out_val, float* rv, int* ri) {
     const int tid = threadIdx.x;
@@ -403,13 +407,15 @@ __device__ void topk_rounds(float* w, int I, int k0, int K, int* out_idx, float*
 
 // Radix select over n keys (key_at(i), i < n): on return (after a barrier) *s_prefix is the key of the K-th largest
 // and *s_remaining how many keys equal to it belong to the K largest.  All 1024 threads call it.
+// last_pass > 0 stops after the leading bytes: *s_prefix is then the K-th largest key with its low 8 * last_pass bits
+// cleared -- a LOWER BOUND of it, all a pre-filter needs (half the passes and barriers for a few more candidates).
 template <class KeyAt>
 __device__ __forceinline__ void topk_radix_select(KeyAt key_at, int n, int K, int* hist, unsigned* s_prefix,
-                                                  int* s_remaining) {
+                                                  int* s_remaining, int last_pass = 0) {
     const int tid = threadIdx.x;
     if (tid == 0) { *s_prefix = 0u; *s_remaining = K; }
     __syncthreads();
-    for (int p = 3; p >= 0; --p) {
+    for (int p = 3; p >= last_pass; --p) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const unsigned prefix = *s_prefix;
@@ -468,10 +474,11 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
     __shared__ int ri[16];
     __shared__ int hist[256];
     __shared__ unsigned tk[1024];              // per-thread maxima
-    __shared__ unsigned candk[TOPK_NCAND];     // pre-filtered candidates
-    __shared__ int candi[TOPK_NCAND];
+    __shared__ __attribute__((aligned(16))) unsigned candk[TOPK_NCAND];     // pre-filtered candidates
+    __shared__ __attribute__((aligned(16))) int candi[TOPK_NCAND];
     __shared__ unsigned ckey[TOPK_CAP];
     __shared__ int cidx[TOPK_CAP];
+    static_assert(TOPK_CAP == 1024, "cidx doubles as one rank counter per thread");
     __shared__ int tidx[TOPK_CAP];
     __shared__ unsigned s_prefix;
     __shared__ int s_remaining, s_ngt, s_nties, s_ncand;
@@ -492,7 +499,8 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
     //             the LDS bit set (up to 131 072 items) or a copy in `work`, read twice with 4-byte loads.
     const int nseen = seen_off[u + 1] - seen_off[u];
     const bool aligned = (ld & 3) == 0 && ((uintptr_t)scores & 15) == 0;
-    const bool in_regs = K <= TOPK_CAP && I <= 32 * TOPK_MASKW && I <= 4096 * TOPK_RV4 && aligned;
+    // (the STREAM instantiation is only launched beyond 4096 * TOPK_RV4 items: no register-resident row there)
+    const bool in_regs = !STREAM && K <= TOPK_CAP && I <= 32 * TOPK_MASKW && I <= 4096 * TOPK_RV4 && aligned;
     bool streamed = STREAM && K <= TOPK_CAP && !in_regs && aligned && I >= 4096 * TOPK_RV4 && nseen >= 0 && K + nseen <= 1024;
     bool lds_mask = I <= 32 * TOPK_MASKW;
     int* const hset = reinterpret_cast<int*>(maskw);      // streamed: 2048-slot open-addressing set of the seen items
@@ -525,6 +533,18 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
         }
         __syncthreads();
     };
+    // in_regs: the row's loads are issued before the bit set is built (their HBM latency runs beside its two barriers)
+    float4 rowv[TOPK_RV4];
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < TOPK_RV4; ++j) {
+            const int i4 = 4 * (tid + 1024 * j);
+            rowv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i4 < I) rowv[j] = *reinterpret_cast<const float4*>(s + i4);   // (ld % 4 == 0: the 16 bytes are in the row)
+        }
+    }
+    if (tid == 0) { s_ngt = 0; s_nties = 0; s_ncand = 0; }      // (visible behind the barriers of the set-up below)
+    cidx[tid] = 0;                                               // the rank counters of the usual path (TOPK_CAP = 1024)
     if (streamed) {
         for (int i = tid; i < 2048; i += 1024) hset[i] = -1;
         __syncthreads();
@@ -539,11 +559,10 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
                 }
             }
         }
+        __syncthreads();
     } else {
         mask_setup();
     }
-    if (tid == 0) { s_ngt = 0; s_nties = 0; s_ncand = 0; }
-    __syncthreads();
     auto val = [&](int i) -> float {
         if (streamed) { const float v = s[i]; return is_seen(i) ? v - fabsf(v * 1.0f) * 100000000.0f : v; }
         if (!lds_mask) return w[i];
@@ -663,13 +682,13 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
         }
     }
     unsigned keys[TOPK_RV4][4];
+    int wave_r = 65, nw_bound = 0;
     if (in_regs) {
         unsigned m = 0u;
 #pragma unroll
         for (int j = 0; j < TOPK_RV4; ++j) {
             const int i4 = 4 * (tid + 1024 * j);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i4 < I) v = *reinterpret_cast<const float4*>(s + i4);       // (ld % 4 == 0: the 16 bytes are in the row)
+            const float4 v = rowv[j];
             const float e[4] = {v.x, v.y, v.z, v.w};
             const unsigned mw = i4 < I ? maskw[i4 >> 5] >> (i4 & 31) : 0u;   // 4 | i4: the four bits share a word
 #pragma unroll
@@ -680,7 +699,25 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
                 m = k > m ? k : m;
             }
         }
-        tk[tid] = m;
+        // The bound without a selection: the waves whose 64 lanes all hold items (the first nw) each find their r-th
+        // largest maximum, r = ceil(K / nw), to 16 bits -- a binary search on the key's leading bits with ballot + count,
+        // no LDS, no barrier: t ends as the r-th largest with its low half cleared, at least r lanes reach it -- and the
+        // smallest of those is reached by at least nw r >= K maxima.  Looser than the K-th largest of all 1024 maxima
+        // (about twice the candidates), and one barrier instead of the selection's eight.
+        const int nw = I >= 253 ? min(16, (I - 253) / 256 + 1) : 0;
+        wave_r = nw > 0 ? (K + nw - 1) / nw : 65;
+        if (wave_r <= 64) {      // uniform
+            unsigned kth = 0u;
+#pragma unroll
+            for (int b = 31; b >= 16; --b) {
+                const unsigned t = kth | (1u << b);
+                if (__popcll(__ballot(m >= t)) >= wave_r) kth = t;
+            }
+            if ((tid & 63) == 0) hist[tid >> 6] = (int)kth;
+            nw_bound = nw;
+        } else {
+            tk[tid] = m;
+        }
     } else if (!streamed) {
         unsigned m = 0u;
         for (int i = tid; i < I; i += 1024) { const unsigned k = topk_key(val(i)); m = k > m ? k : m; }
@@ -688,8 +725,16 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
     }
     if (!streamed) {
         __syncthreads();
-        topk_radix_select([&](int i) { return tk[i]; }, 1024, K, hist, &s_prefix, &s_remaining);
-        const unsigned bound = s_prefix;
+        unsigned bound;
+        if (nw_bound > 0) {
+            bound = (unsigned)hist[0];
+            for (int w = 1; w < nw_bound; ++w) bound = min(bound, (unsigned)hist[w]);
+        } else {
+            // (register-resident row: the bound from the two leading bytes of the maxima -- scores within 2^-7 relative
+            //  below the K-th largest maximum join the candidates)
+            topk_radix_select([&](int i) { return tk[i]; }, 1024, K, hist, &s_prefix, &s_remaining, in_regs ? 2 : 0);
+            bound = s_prefix;
+        }
         if (in_regs) {
 #pragma unroll
             for (int j = 0; j < TOPK_RV4; ++j)
@@ -714,6 +759,39 @@ __global__ __launch_bounds__(1024) void masked_topk_kernel(const float* __restri
     }
     const int ncand = s_ncand;
     const bool filtered = ncand <= TOPK_NCAND;          // uniform; otherwise (heavy ties) select over all scores
+    if (ncand <= 1024) {         // uniform -- the usual case (K = 100: about 200 candidates)
+        // Rank by counting: a candidate's place in the stable descending order = how many candidates precede it (larger
+        // key, or the same key and a lower item: ONE unsigned 64-bit comparison of (key, ~item)).  All 1024 threads
+        // take part: thread = (candidate i, slice q of the others), slices by wave so that a wave's reads of the others
+        // are broadcasts; the partial counts meet in LDS.  One barrier, no selection, no sort: this replaced the second
+        // radix select (4 passes, 12 barriers), the collect and a 28-stage bitonic sort.
+        int P2 = 64;
+        while (P2 < ncand) P2 <<= 1;
+        const int parts = 1024 / P2, i = tid & (P2 - 1), q = tid / P2;
+        const int chunk = (((ncand + parts - 1) / parts) + 3) & ~3;
+        const int j0 = q * chunk, j1 = min(ncand, j0 + chunk);
+        if (i < ncand && j0 < j1) {
+            const unsigned long long ca = ((unsigned long long)candk[i] << 32) | (unsigned)~candi[i];
+            int rank = 0;
+            int j = j0;
+#define SV_PRECEDES(k_, i_) ((((unsigned long long)(k_) << 32) | (unsigned)~(i_)) > ca)
+#pragma unroll 2
+            for (; j + 4 <= j1; j += 4) {
+                const uint4 kb = *reinterpret_cast<const uint4*>(&candk[j]);
+                const int4 ib = *reinterpret_cast<const int4*>(&candi[j]);
+                rank += SV_PRECEDES(kb.x, ib.x) + SV_PRECEDES(kb.y, ib.y) + SV_PRECEDES(kb.z, ib.z) + SV_PRECEDES(kb.w, ib.w);
+            }
+            for (; j < j1; ++j) rank += SV_PRECEDES(candk[j], candi[j]);
+#undef SV_PRECEDES
+            atomicAdd(&cidx[i], rank);
+        }
+        __syncthreads();
+        if (tid < ncand) {
+            const int rank = cidx[tid];
+            if (rank < K) { oi[rank] = candi[tid]; ov[rank] = topk_unkey(candk[tid]); }
+        }
+        return;
+    }
     if (filtered) topk_radix_select([&](int i) { return candk[i]; }, ncand, K, hist, &s_prefix, &s_remaining);
     else topk_radix_select([&](int i) { return topk_key(val(i)); }, I, K, hist, &s_prefix, &s_remaining);
     const unsigned T = s_prefix;
