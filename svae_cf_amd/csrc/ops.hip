@@ -351,18 +351,21 @@ __global__ void gather_rows_kernel(const float* __restrict__ in, const int* __re
 // score_i = s_i - |s_i * m_i| * 1e8, m = one-hot of the user's INPUT items.  One workgroup per user.
 // Result = the first K entries of a stable descending sort: ties -> lower item index first.
 //
-// Radix select instead of K rounds of arg-max (the first version: 100 sweeps over the row with two barriers each,
-// 300 us per batch of 256 users at 20k items -- a hundred times the row's HBM time):
-//   1. work[] = masked scores; every score becomes an order-preserving 32-bit key;
-//   2. pre-filter: the K-th largest of the 1024 per-thread maxima bounds the K-th largest score from below; the
-//      scores that reach it (a few hundred) are collected in LDS;
-//   3. four histogram passes over those (8 bits each, LDS atomics) find the key T of the K-th largest score and
-//      how many scores equal to T belong to the result (histogramming ALL scores four times serialised on a few
-//      hot bins: 40 us per batch of 256 users);
-//   4. the scores above T (fewer than K) are sorted by (key descending, item ascending) with a bitonic network in
-//      LDS, the items whose score equals T by item; the lists are written out.
-// Three reads of the row, all but the first from L2.  K > TOPK_CAP or more than TOPK_CAP ties at the threshold fall
-// back to the arg-max rounds (degenerate inputs: e.g. a constant row).
+// History: K rounds of arg-max (100 sweeps over the row with two barriers each: 300 us per batch of 256 users at 20k
+// items, a hundred times the row's HBM time) -> radix selects + a bitonic sort (rounds 1-2: 17 us) -> round 3:
+//   1. the row is read ONCE into registers (16 bytes per lane; catalogues up to 24 576 items -- larger ones stream
+//      through registers in chunks, see STREAM), its loads issued before the seen items are set as bits in LDS; every
+//      masked score becomes an order-preserving 32-bit key;
+//   2. pre-filter bound: every wave finds its ceil(K / 16)-th largest per-thread maximum to 16 bits by a binary search
+//      on the key's leading bits (ballot + count; no LDS); the smallest of the 16 results is reached by at least K
+//      maxima, so by at least K scores; the ~200 scores that reach it are collected in LDS;
+//   3. a candidate's place in the result = how many candidates precede it (larger key, or equal key and lower item):
+//      counted by all threads over (candidate, slice of the others) pairs, partial counts met in LDS; places < K are
+//      written out.  Four barriers in all.
+// Fallbacks, all exact: small catalogues / large K (fewer than 64 maxima per contributing wave) take the bound from a
+// radix select over the 1024 maxima; more than 1024 candidates (heavy ties, adversarial layouts) go through a radix
+// select for the K-th key + a bitonic sort of the keys above it; K > TOPK_CAP or more than TOPK_CAP ties at the
+// threshold fall back to the arg-max rounds (degenerate inputs: e.g. a constant row).
 // ------------------------------------------------------------------------------------------------
 constexpr int TOPK_CAP = 1024;
 

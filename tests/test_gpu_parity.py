@@ -391,6 +391,20 @@ def test_masked_topk_equals_stable_descending_sort_on_edge_cases():
     small = torch.randn(3, 50, generator=g)
     run(small, [[], [1], [2, 3]], 50)
     run(torch.randn(2, 3000, generator=g), [[], []], 2000)             # K above the LDS sort: arg-max rounds
+    # ---- the register-resident form's bound (per-wave ballot search, r = ceil(K / full waves) <= 64, else the radix
+    # select) and its places by counting (up to 1 024 candidates, else select + sort): both sides of every switch
+    for I, K in ((20000, 100), (2000, 100), (256, 100), (253, 60), (252, 60), (700, 120), (600, 128), (600, 129),
+                 (20000, 1000), (24576, 1024), (24576, 7)):
+        r = torch.randn(3, I, generator=g)
+        best = torch.topk(r[1], min(200, I // 2)).indices.tolist()
+        run(r, [[], best, list(range(0, I, 5))], K)
+    I = 20000
+    run((torch.randint(0, 2000, (3, I), generator=g).float() - 1000.0) / 7.0, [[], [3, 4], list(range(0, 600, 2))], 100)   # ~10 ties per value
+    desc = -torch.arange(I, dtype=torch.float32).repeat(2, 1)          # the best items all in wave 0's lanes: the other
+    run(desc, [[], [0, 1, 2, 50]], 100)                                 # waves pull the bound down (thousands of candidates)
+    block = torch.randn(2, I, generator=g)
+    block[:, 4096:8192] += 6.0                                          # one float4 slot of every thread far above the rest
+    run(block, [[], list(range(4096, 4300))], 100)
     # ---- catalogues beyond 24 576 items: the STREAMED path (round 3: the row read once in register-resident chunks, the
     # seen items in a hash set, the bound tightened by selecting over the candidate list)
     for I in (24580, 30000, 131072 + 4, 200000):
