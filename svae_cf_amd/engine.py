@@ -8,6 +8,7 @@ and nothing synchronises with the host (the loss stays on the device until asked
 Reference path replaced: Model.forward nb:752-768, VAELoss.forward nb:795-812,
 loss.backward() nb:1205, optimizer.step() nb:1206, scoring in evaluate() nb:615-636.
 """
+import contextlib
 import math
 import os
 import threading
@@ -118,6 +119,13 @@ class SVAEEngine:
         self.loss_out = torch.zeros(4, **f32)
         self.cap = 0
         self.ws = {}
+        # scoring sessions (scoring_session / score(slot=1)): a second, forward-only workspace so that two batches can be
+        # scored beside each other on two streams; `_session` promises that the parameters do not change
+        self._session = False
+        self._session_ready = None
+        self._slot = 0
+        self._slot_main = None         # (ws, loss_out) of slot 0 while slot 1 is current
+        self._slot1 = None             # (ws, loss_out, cap) of slot 1
         # row splits of the weight-gradient GEMMs (end of round 2, tools/sweep_env.sh, ms per step on one box, two
         # rounds: 32 -> 0.868 / 0.870, 16 -> 0.867 / 0.870, 24 -> 0.868 / 0.869, 21 -> 0.881 / 0.879, 48 -> 0.883 / 0.881)
         self.nsplit = int(_opt("SVAE_NSPLIT", "32"))
@@ -274,41 +282,112 @@ class SVAEEngine:
     def _ensure(self, R):
         if R <= self.cap:
             return
+        if self._slot != 0:
+            raise RuntimeError("the workspace grows on slot 0 only (score() sizes it before it switches slots)")
         if self._w3_event is not None:     # floated kernels still read the workspace that is about to be replaced
             self._settle()
             torch.cuda.current_stream().synchronize()
+        if self._session:                  # another slot's kernels may still be running on another stream
+            torch.cuda.synchronize(self.device)
         cap = int(R * 1.25) + 64
-        f32 = dict(device=self.device, dtype=torch.float32)
-        shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dgh=G, dg4=4 * HP, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
-                      logits=self.IP, dz=L, dtmp=2 * L, dd1=DP, denc=DP, dhs=HP, dgi=G, demb=E,
-                      kl_row=1, nll_row=1, lse=1)
-        shapes["logits"] = 0                      # allocated on demand (_ensure_logits): fused mode never needs it
-        self.ws = {k: torch.empty(cap * w, **f32) for k, w in shapes.items()}
+        self.ws = self._new_ws(cap)
         self.cap = cap
         if self.fused:
-            bf = dict(device=self.device, dtype=torch.bfloat16)
-            capp = (cap + 63) // 64 * 64
-            self.capp = capp
-            self.ws["dg4b"] = torch.zeros((cap + 1) * 4 * HP, **bf)
-            self.ws["emb16"] = torch.zeros((cap + 1) * E, **bf)       # the gathered rows as bf16 (self.emb16)
-            self.ws["hprev16"] = torch.zeros((cap + 1) * HP, **bf)    # the previous hidden states as bf16 (self.wgrad_big)
-            # (split instantiation: every bf16 image is followed by its mid and lo parts, one part stride apart)
-            m = 3 if self.split else 1
-            self.ws["h2b"] = torch.zeros(m * capp * DP, **bf)
-            self.ws["h2s"] = torch.zeros(m * capp * DP, **bf)
-            # (transposed images: read by the split instantiation only; the bf16 sweeps transpose on the LDS read)
-            self.ws["h2tb"] = torch.zeros(m * DP * capp, **bf) if self.split else None
-            nsm = _lib.load().svae_proj_ns_max()
-            self.ws["part"] = torch.zeros(nsm * capp * 2, **f32)
-            self.ws["mpart"] = torch.zeros(nsm * capp, **f32)
-            self.ws["pslabs"] = torch.empty(nsm * capp * DP, **f32)
-            self.ws["pslabs_side"] = torch.empty(nsm * self.IPAD * DP, **f32)
+            self.capp = (cap + 63) // 64 * 64
             if self.w3b is None:
+                bf = dict(device=self.device, dtype=torch.bfloat16)
+                m = 3 if self.split else 1
                 self.wih_frags = [torch.zeros(m * _lib.load().svae_rowgemm_frag_elems(i), **bf) for i in (0, 1)]
                 self.mlp_frags = torch.zeros(m * _lib.load().svae_mlp_frag_elems(), **bf)
                 self.w3b = torch.zeros(m * self.IPAD * DP, **bf)
                 self.w3s = torch.zeros(m * self.IPAD * DP, **bf)
                 self.w3tb = torch.zeros(m * DP * self.IPAD, **bf) if self.split else None
+
+    # what only backward writes or reads: a forward-only workspace (slot 1 of a scoring session) leaves them empty
+    _BACKWARD_ONLY = ("dgh", "dg4", "dz", "dtmp", "dd1", "denc", "dhs", "dgi", "demb", "dg4b", "hprev16", "mpart",
+                      "pslabs", "pslabs_side")
+
+    def _new_ws(self, cap, forward_only=False):
+        f32 = dict(device=self.device, dtype=torch.float32)
+        shapes = dict(emb=E, gi=G, hs=HP, hprev=HP, gates4=4 * HP, dgh=G, dg4=4 * HP, enc=DP, tmp=2 * L, eps=L, z=L, d1=DP,
+                      logits=self.IP, dz=L, dtmp=2 * L, dd1=DP, denc=DP, dhs=HP, dgi=G, demb=E,
+                      kl_row=1, nll_row=1, lse=1)
+        shapes["logits"] = 0                      # allocated on demand (_ensure_logits): fused mode never needs it
+        ws = {k: torch.empty(cap * w, **f32) for k, w in shapes.items()}
+        if self.fused:
+            bf = dict(device=self.device, dtype=torch.bfloat16)
+            capp = (cap + 63) // 64 * 64
+            ws["dg4b"] = torch.zeros((cap + 1) * 4 * HP, **bf)
+            ws["emb16"] = torch.zeros((cap + 1) * E, **bf)       # the gathered rows as bf16 (self.emb16)
+            ws["hprev16"] = torch.zeros((cap + 1) * HP, **bf)    # the previous hidden states as bf16 (self.wgrad_big)
+            # (split instantiation: every bf16 image is followed by its mid and lo parts, one part stride apart)
+            m = 3 if self.split else 1
+            ws["h2b"] = torch.zeros(m * capp * DP, **bf)
+            ws["h2s"] = torch.zeros(m * capp * DP, **bf)
+            # (transposed images: read by the split instantiation only; the bf16 sweeps transpose on the LDS read)
+            ws["h2tb"] = torch.zeros(m * DP * capp, **bf) if self.split else None
+            nsm = _lib.load().svae_proj_ns_max()
+            ws["part"] = torch.zeros(nsm * capp * 2, **f32)
+            ws["mpart"] = torch.zeros(nsm * capp, **f32)
+            ws["pslabs"] = torch.empty(nsm * capp * DP, **f32)
+            ws["pslabs_side"] = torch.empty(nsm * self.IPAD * DP, **f32)
+        if forward_only:
+            for k in self._BACKWARD_ONLY:
+                if k in ws:
+                    ws[k] = torch.empty(0, device=self.device, dtype=ws[k].dtype)
+        return ws
+
+    def _use_slot(self, k):
+        """Make workspace `k` (0: the engine's own; 1: the forward-only second one of a scoring session) current."""
+        if k == self._slot:
+            return
+        if k == 1:
+            if self._slot1 is None or self._slot1[2] != self.cap:
+                if self._slot1 is not None:            # (grown: its kernels may still be running)
+                    torch.cuda.synchronize(self.device)
+                self._slot1 = (self._new_ws(self.cap, forward_only=True), torch.zeros_like(self.loss_out), self.cap)
+            self._slot_main = (self.ws, self.loss_out)
+            self.ws, self.loss_out = self._slot1[0], self._slot1[1]
+        else:
+            self.ws, self.loss_out = self._slot_main
+            self._slot_main = None
+        self._slot = k
+
+    @contextlib.contextmanager
+    def scoring_session(self):
+        """Scoring many batches with unchanged parameters (evaluate()).  The caller promises that nothing writes the
+        parameters between enter and exit; in return everything ``score`` derives from the parameters alone -- the MLP
+        and W_ih weight fragments, the bf16 images of decoder.linear2 (35 us of a 480 us call at the ML-20M shape) -- is
+        made ONCE here, on the current stream, and ``score(..., slot=1)`` may run on a second stream beside slot 0:
+        the slots share those read-only images and nothing else (own workspace, own loss scalars), so the recurrence of
+        one batch (a quarter of the chip) runs beside the sweep of the other.  ``scoring_stream()`` names a stream that
+        runs concurrently with the current one.  Fused modes only; elsewhere the session changes nothing."""
+        if not self.fused or self._session:
+            yield self
+            return
+        self._settle()
+        cur = torch.cuda.current_stream()
+        self._ensure(1)
+        with _Launch(cur):
+            self._param_prep(False)
+            if self.rowgemm:
+                _lib.call("svae_rowgemm_prep_prec", self.P("gru.weight_ih_l0").data_ptr(), 0, self.wih_frags[0].data_ptr(),
+                          self.prec, _stream())
+        self._session_ready = self._sev("scoring_session")
+        self._session_ready.record(cur)
+        self._session = True
+        try:
+            yield self
+        finally:
+            self._session = False
+            self._use_slot(0)
+
+    def scoring_stream(self):
+        """A stream that runs concurrently with the current one (the engine's measured side stream), for slot 1 of a
+        scoring session; None where the engine has none (no overlap, non-fused modes)."""
+        if not (self.fused and self.overlap):
+            return None
+        return self._side_stream(cur=torch.cuda.current_stream())
 
     def _ps(self, which):
         """Part stride (elements) of the bf16 operand images: 'rows' (h2b / h2s / h2tb) or 'items' (w3b / w3s / w3tb);
@@ -566,7 +645,10 @@ class SVAEEngine:
             if eps.numel() != R * L:
                 raise ValueError("eps must have %d x %d elements" % (R, L))
             w["eps"][:R * L].copy_(eps.reshape(-1))
-        if self.fused and self.overlap:
+        # scoring session: the parameter-derived operands exist already and are shared with the other slot (read-only);
+        # nothing goes to the side stream -- the other slot may be running there
+        sess = bool(self._session and self.fused and not want_grad)
+        if self.fused and self.overlap and not sess:
             side = self._side_stream(cur=cur)
             step_begin = self._sev("step_begin")
             step_begin.record(cur)
@@ -594,7 +676,13 @@ class SVAEEngine:
         e16 = (head_fused and self.emb16 and self.gru_prec == PREC_BF16 and self.merged_dg and self.dg_bf16
                and not self.bptt_split and want_loss)
         self._emb16_live = bool(e16)
-        if head_fused:
+        if sess:
+            _lib.stream_wait(cur, self._session_ready)
+            head_fused = False                    # (the W_ih fragments were made when the session began)
+        if sess and e16:
+            _lib.call("svae_embed_fwd_bf16", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
+                      w["emb16"].data_ptr(), R, self.I, st)
+        elif head_fused:
             # gather + W_ih fragments in one launch (both head the step, neither needs the other)
             _lib.call("svae_embed_fwd_wih_prep", self.P("item_embed.weight").data_ptr(), plan.x.data_ptr(),
                       (w["emb16"] if e16 else w["emb"]).data_ptr(), gi_split if gi_split else R, self.I,
@@ -605,7 +693,7 @@ class SVAEEngine:
         if self.fused and self.rowgemm:
             # W_ih fragments are built here, on the caller's stream (the GEMM is the second kernel of the step: the
             # side stream's preparation would not be ready in time), 2 us
-            if not head_fused:
+            if not head_fused and not sess:
                 _lib.call("svae_rowgemm_prep_prec", self.P("gru.weight_ih_l0").data_ptr(), 0,
                           self.wih_frags[0].data_ptr(), self.prec, st)
             ev = self._tic("gi_gemm")
@@ -625,7 +713,7 @@ class SVAEEngine:
                        bias=self.P("gru.bias_ih_l0"))
         # Two time ranges (batch.choose_time_split): the recurrence of steps >= t1 runs on the side stream beside
         # the decoder side of the rows of steps < t1 (rows are time-major: the first r1 of them).
-        side_prep = self.fused and self.overlap
+        side_prep = self.fused and self.overlap and not sess
         t1, r1 = (plan.split_t, plan.split_r) if (self.time_split and side_prep and want_loss
                                                   and want_grad and self.gru_prec in (PREC_BF16, PREC_SPLIT)) else (0, 0)
 
@@ -704,7 +792,7 @@ class SVAEEngine:
             # encoder -> (mu | log_sigma) -> z, KL -> decoder hidden in one kernel (bf16 MFMA mode)
             if params_ready is not None:
                 _lib.stream_wait(cur, params_ready)
-            else:
+            elif not sess:
                 self._param_prep(want_grad)
             if self._w3_event is not None:
                 # the last step's floated decoder.linear2 work: it read d1 / h2b / h2tb, which the kernels below
@@ -1542,10 +1630,23 @@ class SVAEEngine:
         return self.loss_out
 
     # ------------------------------------------------------------------ scoring
-    def score(self, plan, topk=100, eps=None, seed=0, step=0):
+    def score(self, plan, topk=100, eps=None, seed=0, step=0, slot=0):
         """evaluate()'s per-user work (nb:615-636): loss at anneal 0.2 over all rows, then the LAST
         timestep's logits with the user's input items masked, ranked top-k.
-        Returns (loss_out, idx [B, k] int32, val [B, k]) in the plan's SORTED user order."""
+        Returns (loss_out, idx [B, k] int32, val [B, k]) in the plan's SORTED user order.
+        slot = 1 (inside ``scoring_session`` only): the call works in the engine's second workspace, so that it may be
+        issued on another stream while a slot-0 call is still running; its loss_out is the slot's own."""
+        if slot not in (0, 1) or (slot == 1 and not self._session):
+            raise ValueError("score(slot=1) needs an open scoring_session()")
+        self._use_slot(0)
+        self._ensure(plan.R)                      # (the workspace grows on slot 0; slot 1 follows its size)
+        self._use_slot(slot)
+        try:
+            return self._score(plan, topk, eps, seed, step)
+        finally:
+            self._use_slot(0)
+
+    def _score(self, plan, topk, eps, seed, step):
         self.forward(plan, 0.2, eps=eps, seed=seed, step=step, want_grad=False)
         B, st = plan.B, _stream()
         k = int(min(topk, self.I))

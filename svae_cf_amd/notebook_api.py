@@ -624,15 +624,29 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
     hflat_d = torch.from_numpy(hflat).to(eng.device)
     hoff_d = torch.from_numpy(hoff).to(eng.device)
     rank_dev = torch.full((max(1, len(hflat)),), -2, device=eng.device, dtype=torch.int32)
-    for ci, (s0, plan) in enumerate(zip(my_starts, plans)):
-        n = plan.B
-        eps = None
-        if eps_list is not None:
-            eps = torch.from_numpy(pack_rows(plan, eps_list[s0:s0 + n], L)).to(eng.device)
-        out, idx, _, _ = eng.score(plan, kmax, eps=eps, seed=seed, step=s0)
-        loss_dev[ci].copy_(out[0])
-        _lib.call("svae_heldout_ranks", idx.data_ptr(), n, int(idx.shape[1]), plan.row_key.data_ptr(), plan.last_row.data_ptr(),
-                  hflat_d.data_ptr(), hoff_d.data_ptr(), len(pairs), rank_dev.data_ptr(), _stream())
+    # The parameters do not change in here: one scoring session (the parameter-derived operands made once) and two
+    # workspaces -- even batches on the caller's stream, odd ones on a second stream beside them, so that the
+    # recurrence of one batch (a quarter of the chip) runs beside the sweep of the other.
+    cur = torch.cuda.current_stream()
+    with eng.scoring_session():
+        second = eng.scoring_stream() if len(my_starts) > 1 else None
+        lanes = [cur] if second is None else [cur, second]
+        if second is not None:
+            second.wait_stream(cur)               # (the arrays above were filled on the caller's stream)
+        for ci, (s0, plan) in enumerate(zip(my_starts, plans)):
+            n = plan.B
+            slot = ci % len(lanes)
+            with torch.cuda.stream(lanes[slot]):
+                eps = None
+                if eps_list is not None:
+                    eps = torch.from_numpy(pack_rows(plan, eps_list[s0:s0 + n], L)).to(eng.device)
+                out, idx, _, _ = eng.score(plan, kmax, eps=eps, seed=seed, step=s0, slot=slot)
+                loss_dev[ci].copy_(out[0])
+                _lib.call("svae_heldout_ranks", idx.data_ptr(), n, int(idx.shape[1]), plan.row_key.data_ptr(),
+                          plan.last_row.data_ptr(), hflat_d.data_ptr(), hoff_d.data_ptr(), len(pairs), rank_dev.data_ptr(),
+                          _stream())
+        if second is not None:
+            cur.wait_stream(second)
     t_loop = time.perf_counter()
     rank_all = rank_dev.cpu().numpy()
     t_sync = time.perf_counter()

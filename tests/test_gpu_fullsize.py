@@ -514,6 +514,71 @@ def test_scoring_does_not_depend_on_the_batch_before_it():
         assert torch.equal(a, b)
 
 
+def test_scoring_session_on_two_lanes_equals_call_by_call_scoring():
+    """engine.scoring_session(): parameter-derived operands made once, batches alternating between the engine's two
+    workspaces on two streams (what notebook_api.evaluate does).  Six batches of unequal size -- the largest LAST, so the
+    workspaces grow inside the session -- against the same batches scored one call at a time outside a session: loss,
+    top-100 ids and values bit-identical; the poisoned variant fills both workspaces with NaN between two passes (a
+    slot must not read what the batch before left).  A training step after the session sees fresh operands again."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    I = 20000
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
+    sizes = [96, 64, 128, 32, 80, 200]
+    users = synth.make_users(sum(sizes), I, mu, sigma, lmax, seed=79)
+    plans, at = [], 0
+    for n in sizes:
+        plans.append(S.build_plan(users[at:at + n], 4, user_keys=np.arange(at, at + n), device="cuda", total_items=I))
+        at += n
+    eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
+    _init(eng, 22)
+    for p in plans:
+        eng.prepare(p, scoring=True)
+    ref = []
+    for k, p in enumerate(plans):
+        loss, idx, val, _ = eng.score(p, 100, seed=3, step=k)
+        ref.append((loss.clone(), idx.clone(), val.clone()))
+    torch.cuda.synchronize()
+    eng2 = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)        # a fresh engine: its workspaces start empty
+    _init(eng2, 22)
+    with pytest.raises(ValueError):
+        eng2.score(plans[0], 100, slot=1)                          # slot 1 outside a session
+    cur = torch.cuda.current_stream()
+    for poisoned in (False, True):
+        got = []
+        with eng2.scoring_session():
+            second = eng2.scoring_stream()
+            assert second is not None
+            second.wait_stream(cur)
+            for k, p in enumerate(plans):
+                with torch.cuda.stream((cur, second)[k & 1]):
+                    loss, idx, val, _ = eng2.score(p, 100, seed=3, step=k, slot=k & 1)
+                    got.append((loss.clone(), idx.clone(), val.clone()))
+            cur.wait_stream(second)
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(zip(ref, got)):
+            for x, y in zip(a, b):
+                assert torch.isfinite(y.float()).all(), (poisoned, k)
+                assert torch.equal(x, y), (poisoned, k)
+        if not poisoned:
+            for ws in (eng2.ws, eng2._slot1[0]):
+                for v in ws.values():
+                    if v is not None and v.numel() and v.dtype == torch.float32:
+                        v.fill_(float("nan"))
+            torch.cuda.synchronize()
+    assert eng2._slot == 0 and not eng2._session
+    # the session's cached operands do not outlive it: a training step, then call-by-call scoring = the same on `eng`
+    tp = S.build_plan(users[:64], 4, user_keys=np.arange(64), device="cuda", total_items=I)
+    for e in (eng, eng2):
+        e.train_step(tp, 0.1, seed=5, step=0)
+    a = eng.score(plans[1], 100, seed=3, step=1)
+    with eng2.scoring_session():
+        b = eng2.score(plans[1], 100, seed=3, step=1)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert not torch.equal(a[0], ref[1][0])                        # (the step did change the parameters)
+
+
 def test_side_streams_are_not_held_behind_the_callers_dispatch():
     """HIP maps a process's streams onto 4 hardware queues; two streams on one queue still run CONCURRENTLY (no barrier
     between their packets) but are DISPATCHED in order, so a 4 000-workgroup finish kernel or optimizer launch on one

@@ -30,6 +30,33 @@ for _ in range(3):
         n += p.B
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+
+
+# the same plans inside a scoring session: parameter-derived operands made once, batches alternating between two
+# workspaces on two streams (what notebook_api.evaluate does)
+def session_pass(reps):
+    cur = torch.cuda.current_stream()
+    with eng.scoring_session():
+        second = eng.scoring_stream()
+        lanes = [cur] if second is None else [cur, second]
+        if second is not None:
+            second.wait_stream(cur)
+        k = 0
+        for _ in range(reps):
+            for p in plans:
+                with torch.cuda.stream(lanes[k % len(lanes)]):
+                    eng.score(p, 100, seed=1, slot=k % len(lanes))
+                k += 1
+        if second is not None:
+            cur.wait_stream(second)
+
+
+session_pass(1)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+session_pass(3)
+torch.cuda.synchronize()
+dt_session = time.perf_counter() - t0
 # the top-k kernel alone
 st = torch.cuda.current_stream().cuda_stream
 p = plans[0]
@@ -118,6 +145,7 @@ end_to_end = {"entry_point": "notebook_api.evaluate(batch_size=%d)" % B, "users"
 print(json.dumps({"metric": "users scored/s (ML-20M shape, top-100)", "value": n / dt, "batch": B, "items": I,
                   "evaluate_end_to_end": end_to_end,
                   "ms_per_batch": dt / (3 * len(plans)) * 1e3,
+                  "scoring_session_two_lanes": {"users_per_s": n / dt_session, "ms_per_batch": dt_session / (3 * len(plans)) * 1e3},
                   "masked_topk": {"us": us, "algorithmic_bytes": algo, "GB/s": algo / us / 1e3,
                                   "frac_of_8TB/s": algo / us / 1e3 / 8000.0},
                   "masked_topk_2048_users": {"us": us_big, "GB/s": 8 * algo / us_big / 1e3,
