@@ -415,7 +415,28 @@ def main():
         torch.cuda.synchronize()
         topk_ms = e0.elapsed_time(e1) / nrep
         tb = float(p0.B) * I * 4
+        # the way notebook_api.evaluate scores: one scoring session, batches alternating between the engine's two
+        # workspaces on two streams
+        cur_s = torch.cuda.current_stream()
+        some = plans[:8]
+        lanes_ms = None
+        with eng.scoring_session():
+            second = eng.scoring_stream()
+            if second is not None:
+                second.wait_stream(cur_s)
+                for timed in (False, True):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for k_, p_ in enumerate(some * (3 if timed else 1)):
+                        with torch.cuda.stream((cur_s, second)[k_ & 1]):
+                            eng.score(p_, topk=100, seed=3, slot=k_ & 1)
+                    cur_s.wait_stream(second)
+                    torch.cuda.synchronize()
+                    lanes_ms = (time.perf_counter() - t0) * 1e3 / (3 * len(some))
         ev_leg = dict(users=p0.B, rows=p0.R, score_ms=score_ms, users_per_s=p0.B / (score_ms * 1e-3),
+                      two_lanes=(None if lanes_ms is None else dict(
+                          ms_per_batch=lanes_ms, users_per_s=sum(p_.B for p_ in some) / len(some) / (lanes_ms * 1e-3),
+                          note="scoring_session(): two batches in flight on two streams, 8 plans x 3")),
                       topk=dict(kernel="svae_masked_topk (k=100)", ms=topk_ms, algorithmic_bytes=tb, bound="hbm",
                                 achieved=tb / (topk_ms * 1e-3) / 1e9, peak=PEAK["hbm"], unit="GB/s",
                                 frac=tb / (topk_ms * 1e-3) / 1e9 / PEAK["hbm"]))
