@@ -132,17 +132,35 @@ def load():
         fn.restype = _I
     lib.svae_last_error.argtypes = []
     lib.svae_last_error.restype = _c.c_char_p
+    # The same library once more through a handle that KEEPS the interpreter lock during a call (`call` below).
+    global _lib_locked
+    locked = ctypes.PyDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(locked, name)
+        fn.argtypes = argtypes
+        fn.restype = _I
+    _lib_locked = locked
     _lib = lib
     return lib
 
 
+_lib_locked = None
 _fns = {}
+# `call` is the launch path of the engine: entry points that enqueue a kernel or an event and return in a few
+# microseconds.  Through ctypes.CDLL every one of them drops the interpreter lock and has to win it back -- with plan
+# builder threads running beside the loop (batch.PlanPrefetcher) each of the ~50 launches of a step or ~17 of a scoring
+# call then waits for a builder's Python stretch: measured in evaluate(), a scoring call's host time went from 0.12 ms
+# alone to 0.2-0.4 ms with two or three builders (tools/probe/evaluate_workers.py), and the loop became host-bound.
+# So launches keep the lock (ctypes.PyDLL); entry points that can block on the device or on other ranks do not.
+_UNLOCKED_PREFIXES = ("svae_rccl_", "svae_allreduce_", "svae_allgather_", "svae_reduce_scatter_", "svae_event_elapsed",
+                      "svae_plan_", "svae_proj_schedule")
 
 
 def call(name, *args):
     fn = _fns.get(name)
     if fn is None:
-        fn = _fns[name] = getattr(load(), name)
+        lib = load()
+        fn = _fns[name] = getattr(lib if name.startswith(_UNLOCKED_PREFIXES) else _lib_locked, name)
     rc = fn(*args)
     if rc != 0:
         msg = load().svae_last_error().decode("utf-8", "replace")

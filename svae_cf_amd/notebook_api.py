@@ -564,6 +564,20 @@ def _metrics_from_rankings(rec, held_lists, n_inputs, Ks=(10, 100)):
     return sums, len_map
 
 
+EVAL_PLAN_CACHE_BYTES = 1 << 30      # device bytes of resident evaluation plans kept per reader (evaluate)
+
+
+class _ResidentPlans:
+    """The iterable evaluate() reads its plans from when they are already on the device (PlanPrefetcher's face)."""
+    wait_s = 0.0
+
+    def __init__(self, plans):
+        self.plans = plans
+
+    def __iter__(self):
+        return iter(self.plans)
+
+
 def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=256, eps_list=None, seed=0,
              rank=0, world=1, group=None, workers=2):
     """nb:594-666.  Returns (metrics dict with the reference's 7 keys, len_to_ndcg_at_100_map).
@@ -578,6 +592,10 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
     stay on the device until the end, and so does the hit search of nb:636-645 (``svae_heldout_ranks``: the position of
     every held-out item in its user's top-100); one read-back at the end feeds the float64 metric arithmetic of
     nb:637-654 for all users.  Nothing synchronises per batch.
+
+    Later calls on the same reader (fit() evaluates every epoch) find their plans resident on the device
+    (``reader._svae_eval_plans``, up to EVAL_PLAN_CACHE_BYTES) and start no builder threads; the batches are scored
+    two at a time on two streams inside one ``engine.scoring_session()``.
 
     world > 1 (data parallel, torch.distributed initialised): the user batches are dealt round-robin to the ranks,
     every rank scores its share, and the per-user metric rows (7 float64 per user) and per-batch loss sums are
@@ -614,8 +632,18 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
     my_starts = [s for ci, s in enumerate(starts) if ci % world == rank]
     csr, hflat, hoff = cache[2], cache[3], cache[4]
     batches = [np.arange(s, min(s + batch_size, len(pairs)), dtype=np.int64) for s in my_starts]
-    plans = PlanPrefetcher(batches, csr, k, eng.device, total_items=eng.I,
-                           prepare=lambda p_: eng.prepare(p_, scoring=True), workers=workers, depth=2 * max(1, workers))
+    # An evaluation's batches are the same at every call (the users in reader order): their plans stay ON THE DEVICE,
+    # kept on the reader beside the lists above, and every call after the first scores resident plans (fit() evaluates
+    # two readers per epoch).  Up to EVAL_PLAN_CACHE_BYTES per reader; larger readers build their plans at every call.
+    pkey = (int(batch_size), int(k), int(rank), int(world), int(eng.I), str(eng.device), id(eng))
+    held = getattr(reader, "_svae_eval_plans", None)
+    if held is not None and held[0] == pkey and held[1] is cache:
+        plans = _ResidentPlans(held[2])
+    else:
+        plans = PlanPrefetcher(batches, csr, k, eng.device, total_items=eng.I,
+                               prepare=lambda p_: eng.prepare(p_, scoring=True), workers=workers, depth=2 * max(1, workers))
+        held = None
+    keep, keep_bytes = ([], 0) if held is None else (None, 0)
     kmax = max(Ks)
     t_begin = time.perf_counter()
     loss_dev = torch.zeros(max(1, len(my_starts)), device=eng.device, dtype=torch.float32)
@@ -636,6 +664,9 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
         for ci, (s0, plan) in enumerate(zip(my_starts, plans)):
             n = plan.B
             slot = ci % len(lanes)
+            if keep is not None:
+                keep_bytes += int(plan._buf.numel()) * plan._buf.element_size() if plan._buf is not None else 0
+                keep = keep + [plan] if keep_bytes <= EVAL_PLAN_CACHE_BYTES else None
             with torch.cuda.stream(lanes[slot]):
                 eps = None
                 if eps_list is not None:
@@ -647,6 +678,11 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
                           _stream())
         if second is not None:
             cur.wait_stream(second)
+    if keep is not None and len(keep) == len(my_starts) and eps_list is None:
+        try:
+            reader._svae_eval_plans = (pkey, cache, keep)
+        except AttributeError:
+            pass
     t_loop = time.perf_counter()
     rank_all = rank_dev.cpu().numpy()
     t_sync = time.perf_counter()

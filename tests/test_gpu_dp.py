@@ -180,6 +180,29 @@ def test_sharded_evaluate_equals_single_process():
     assert ref[0][0]["NDCG@100"] > 0 and ref[1][0]["loss"] > 0
 
 
+def test_evaluate_keeps_its_plans_on_the_device_between_calls():
+    """evaluate() on the same reader again (fit() does, every epoch): the second call reads the plans the first one left
+    on the device (no builder threads) and returns the same metrics and length map to the last digit; a training step in
+    between changes the metrics but not the plans; another batch size builds new plans."""
+    import svae_cf_amd as S
+    N, hp, model, val_reader, train_reader = _eval_setup()
+    crit = N.VAELoss(hp, model)
+    a = N.evaluate(model, crit, val_reader, hp, False, batch_size=8, seed=3)
+    held = val_reader._svae_eval_plans
+    assert len(held[2]) == 5 and all(p.x.is_cuda for p in held[2])
+    b = N.evaluate(model, crit, val_reader, hp, False, batch_size=8, seed=3)
+    assert val_reader._svae_eval_plans is held                       # (nothing was rebuilt)
+    assert a[0] == b[0] and a[1] == b[1]
+    c = N.evaluate(model, crit, val_reader, hp, False, batch_size=16, seed=3)
+    assert val_reader._svae_eval_plans is not held and len(val_reader._svae_eval_plans[2]) == 3
+    # (c differs from a: the latent noise is keyed by (seed, first user of the batch, user), so it moves with the batching)
+    users = [np.asarray(f) for f in train_reader.data[:8]]
+    plan = S.build_plan(users, 4, device="cuda", total_items=I)
+    model.engine.train_step(plan, 0.1, seed=1, step=0)
+    d = N.evaluate(model, crit, val_reader, hp, False, batch_size=16, seed=3)
+    assert d[0]["loss"] != c[0]["loss"]
+
+
 # ---------------------------------------------------------------------------------------------
 # the C-ABI's own collectives (svae_rccl_* / svae_allreduce_sum_f32 / reduce-scatter / all-gather): RCCL at world size 1
 # ---------------------------------------------------------------------------------------------
