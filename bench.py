@@ -420,8 +420,8 @@ def main():
         cur_s = torch.cuda.current_stream()
         some = plans[:8]
         lanes_ms = None
-        with eng.scoring_session():
-            second = eng.scoring_stream()
+        second = eng.scoring_stream()
+        with eng.scoring_session(sweep_cus=None if second is None else eng.two_lane_sweep_cus(p0.B)):
             if second is not None:
                 second.wait_stream(cur_s)
                 for timed in (False, True):

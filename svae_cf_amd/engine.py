@@ -124,6 +124,7 @@ class SVAEEngine:
         self._session = False
         self._session_ready = None
         self._slot = 0
+        self.score_cus = None          # workgroups of the loss-only sweep of `score` (None: the CU count); see scoring_session
         self._slot_main = None         # (ws, loss_out) of slot 0 while slot 1 is current
         self._slot1 = None             # (ws, loss_out, cap) of slot 1
         # row splits of the weight-gradient GEMMs (end of round 2, tools/sweep_env.sh, ms per step on one box, two
@@ -354,17 +355,21 @@ class SVAEEngine:
         self._slot = k
 
     @contextlib.contextmanager
-    def scoring_session(self):
+    def scoring_session(self, sweep_cus=None):
         """Scoring many batches with unchanged parameters (evaluate()).  The caller promises that nothing writes the
         parameters between enter and exit; in return everything ``score`` derives from the parameters alone -- the MLP
         and W_ih weight fragments, the bf16 images of decoder.linear2 (35 us of a 480 us call at the ML-20M shape) -- is
         made ONCE here, on the current stream, and ``score(..., slot=1)`` may run on a second stream beside slot 0:
         the slots share those read-only images and nothing else (own workspace, own loss scalars), so the recurrence of
         one batch (a quarter of the chip) runs beside the sweep of the other.  ``scoring_stream()`` names a stream that
-        runs concurrently with the current one.  Fused modes only; elsewhere the session changes nothing."""
+        runs concurrently with the current one.  sweep_cus: workgroups of the loss-only sweep inside the session (default:
+        one per CU) -- with two batches in flight, a sweep that leaves the other batch's recurrence its CUs (one
+        workgroup per 4 users; a sweep's workgroup and a recurrence's cannot share a CU: LDS) keeps both streams moving.
+        Fused modes only; elsewhere the session changes nothing."""
         if not self.fused or self._session:
             yield self
             return
+        self.score_cus = None if sweep_cus is None else max(8, min(self._ncu, int(sweep_cus)))
         self._settle()
         cur = torch.cuda.current_stream()
         self._ensure(1)
@@ -380,7 +385,14 @@ class SVAEEngine:
             yield self
         finally:
             self._session = False
+            self.score_cus = None
             self._use_slot(0)
+
+    def two_lane_sweep_cus(self, batch_users):
+        """Workgroups of the loss-only sweep when two batches are scored beside each other: the CUs the other batch's
+        recurrence (one workgroup per 4 users) leaves, never under half the chip.  ML-20M shape, B = 256, ms per batch
+        on two lanes: 160: 0.333, 176: 0.330, 192: 0.322, 208: 0.329, 224: 0.331, 256: 0.334."""
+        return max(self._ncu // 2, self._ncu - (int(batch_users) + 3) // 4)
 
     def scoring_stream(self):
         """A stream that runs concurrently with the current one (the engine's measured side stream), for slot 1 of a
@@ -846,7 +858,7 @@ class SVAEEngine:
                 _lib.call("svae_proj_nll_fwd_split", w["h2s"].data_ptr(), self.w3b.data_ptr(), w["d1"].data_ptr(),
                           self.P("decoder.linear2.weight").data_ptr(), self.P("decoder.linear2.bias").data_ptr(),
                           plan.tgt.data_ptr(), R, self.I, plan.K, w["part"].data_ptr(), w["nll_row"].data_ptr(),
-                          w["lse"].data_ptr(), *self._proj_sched(plan, "rows", flat=False), self._ps("rows"),
+                          w["lse"].data_ptr(), *self._proj_sched(plan, "rows", ncu=self.score_cus, flat=False), self._ps("rows"),
                           self._ps("items"), st)
             self._fused_grad = bool(want_grad)
             if defer_loss and want_grad and self.overlap:
@@ -1034,7 +1046,7 @@ class SVAEEngine:
         scoring: the plan will only be scored (``score``: the loss-only sweep over all rows)."""
         if not self.fused:
             return plan
-        want = [("rows", None, None, False)] if scoring else [("rows", None, None, None), ("items", None, None, None)]
+        want = [("rows", None, self.score_cus, False)] if scoring else [("rows", None, None, None), ("items", None, None, None)]
         if not scoring and self.time_split and plan.split_t > 0:
             want += [("rows", plan.split_r, self._range1_cus(plan), None),
                      ("rows", plan.R - plan.split_r, self._ncu, None)]

@@ -656,9 +656,12 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
     # workspaces -- even batches on the caller's stream, odd ones on a second stream beside them, so that the
     # recurrence of one batch (a quarter of the chip) runs beside the sweep of the other.
     cur = torch.cuda.current_stream()
-    with eng.scoring_session():
-        second = eng.scoring_stream() if len(my_starts) > 1 else None
-        lanes = [cur] if second is None else [cur, second]
+    second = eng.scoring_stream()
+    # (the sweep's width does not depend on how many batches THIS rank scores: a batch's loss has the same bits wherever
+    #  it is scored -- the sharded evaluation equals the single-process one exactly)
+    with eng.scoring_session(sweep_cus=None if second is None else eng.two_lane_sweep_cus(batch_size)):
+        lanes = [cur] if second is None or len(my_starts) < 2 else [cur, second]
+        second = second if len(lanes) == 2 else None
         if second is not None:
             second.wait_stream(cur)               # (the arrays above were filled on the caller's stream)
         for ci, (s0, plan) in enumerate(zip(my_starts, plans)):

@@ -34,9 +34,9 @@ dt = time.perf_counter() - t0
 
 # the same plans inside a scoring session: parameter-derived operands made once, batches alternating between two
 # workspaces on two streams (what notebook_api.evaluate does)
-def session_pass(reps):
+def session_pass(reps, sweep_cus=None):
     cur = torch.cuda.current_stream()
-    with eng.scoring_session():
+    with eng.scoring_session(sweep_cus=sweep_cus):
         second = eng.scoring_stream()
         lanes = [cur] if second is None else [cur, second]
         if second is not None:
@@ -57,6 +57,14 @@ t0 = time.perf_counter()
 session_pass(3)
 torch.cuda.synchronize()
 dt_session = time.perf_counter() - t0
+by_cus = {}
+for cus in (160, 176, 192, 208, 224, 240):
+    session_pass(1, cus)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    session_pass(3, cus)
+    torch.cuda.synchronize()
+    by_cus[cus] = (time.perf_counter() - t0) / (3 * len(plans)) * 1e3
 # the top-k kernel alone
 st = torch.cuda.current_stream().cuda_stream
 p = plans[0]
@@ -145,7 +153,8 @@ end_to_end = {"entry_point": "notebook_api.evaluate(batch_size=%d)" % B, "users"
 print(json.dumps({"metric": "users scored/s (ML-20M shape, top-100)", "value": n / dt, "batch": B, "items": I,
                   "evaluate_end_to_end": end_to_end,
                   "ms_per_batch": dt / (3 * len(plans)) * 1e3,
-                  "scoring_session_two_lanes": {"users_per_s": n / dt_session, "ms_per_batch": dt_session / (3 * len(plans)) * 1e3},
+                  "scoring_session_two_lanes": {"users_per_s": n / dt_session, "ms_per_batch": dt_session / (3 * len(plans)) * 1e3,
+                                                "ms_per_batch_by_sweep_workgroups": by_cus},
                   "masked_topk": {"us": us, "algorithmic_bytes": algo, "GB/s": algo / us / 1e3,
                                   "frac_of_8TB/s": algo / us / 1e3 / 8000.0},
                   "masked_topk_2048_users": {"us": us_big, "GB/s": 8 * algo / us_big / 1e3,
