@@ -30,6 +30,7 @@ struct GemmArgs {
     int ktiles_per_split;
     long long slab_stride;
     int nx, ny, nz;     // logical grid: column blocks, row blocks, k-splits
+    int plain;          // block order: 0 = panel groups per XCD (see the kernel), 1 = plain (fewer groups than XCDs)
 };
 
 // Staging is split (register staging, issue-early / write-late): load() puts a thread's 4 float4 of the
@@ -162,7 +163,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     // 250 MB fetched for 80 MB of weight-gradient operands).
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     int bx, by, bz;
-    if (a.nz > 1) {
+    if (a.plain) {
+        // fewer panel groups than XCDs (e.g. the 256 ranked rows of a scoring batch against 20 000 items: two row
+        // panels): one group per XCD would leave the other XCDs without work -- 314 workgroups on 64 CUs, 38 us for a
+        // 20 MB result -- so the blocks are dealt in plain order over the whole chip
+        const int gsize = a.nx * a.ny, mem = blockIdx.x % gsize;
+        bz = blockIdx.x / gsize; bx = mem % a.nx; by = mem / a.nx;
+    } else if (a.nz > 1) {
         const int gsize = a.nx * a.ny, g = xcd + 8 * (slot / gsize), mem = slot % gsize;
         if (g >= a.nz) return;
         bz = g; bx = mem % a.nx; by = mem / a.nx;
@@ -296,7 +303,8 @@ int launch(GemmArgs a, int nsplit, hipStream_t st) {
     a.ny = (a.M + BM - 1) / BM;
     a.nz = nsplit;
     const int ngroups = nsplit > 1 ? nsplit : a.ny, gsize = nsplit > 1 ? a.nx * a.ny : a.nx;
-    dim3 grid(8 * ((ngroups + 7) / 8) * gsize);
+    a.plain = ngroups < 8 ? 1 : 0;
+    dim3 grid(a.plain ? a.nx * a.ny * a.nz : 8 * ((ngroups + 7) / 8) * gsize);
     size_t lds = 2 * (Tile<PREC, AL>::BYTES + Tile<PREC, BL>::BYTES);
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {

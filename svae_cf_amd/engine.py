@@ -800,6 +800,7 @@ class SVAEEngine:
         if eps is None and not eps_done:
             _lib.call("svae_philox_normal", w["eps"].data_ptr(), plan.row_key.data_ptr(), R, int(seed),
                       int(step) & 0xFFFFFFFF, st)
+        rows_prepared = False
         if self.fused:
             # encoder -> (mu | log_sigma) -> z, KL -> decoder hidden in one kernel (bf16 MFMA mode)
             if params_ready is not None:
@@ -830,7 +831,13 @@ class SVAEEngine:
                     _lib.call("svae_loss_reduce", w["nll_row"].data_ptr(), w["kl_row"].data_ptr(), plan.w_nll.data_ptr(),
                               plan.w_kl.data_ptr(), float(anneal), R, self.loss_out.data_ptr(), st)
                 return self.loss_out
-            self._mlp_fwd_rows(0, R)
+            # one time range: the MLP chain, and with it (fused_prep, when a fused sweep follows) the sweep's operand
+            # copies of its last output in the same kernel -- scoring's forward takes this path at every call
+            rows_prepared = bool(want_loss and self.fused_prep)
+            if rows_prepared:
+                self._decoder_rows(plan, 0, R, self._ncu, sweep=False)
+            else:
+                self._mlp_fwd_rows(0, R)
         else:
             self._gemm(w["hs"], self.P("encoder.linear1.weight"), w["enc"], R, DP, HP, HP, HP, DP, 0, 0,
                        bias=self.P("encoder.linear1.bias"), act=1)
@@ -842,7 +849,8 @@ class SVAEEngine:
                        bias=self.P("decoder.linear1.bias"), act=1)
         if self.fused and want_loss:
             self._last_fused = True
-            self._proj_prepare(R)
+            if not rows_prepared:
+                self._proj_prepare(R)
             if want_grad:
                 # forward + hidden-side backward in one sweep over the items (dd1 is ready after this)
                 args = (w["h2s"].data_ptr(), w["h2b"].data_ptr(), self.w3b.data_ptr(), _lib.ptr(self.w3tb),
