@@ -420,23 +420,25 @@ def main():
         cur_s = torch.cuda.current_stream()
         some = plans[:8]
         lanes_ms = None
-        second = eng.scoring_stream()
-        with eng.scoring_session(sweep_cus=None if second is None else eng.two_lane_sweep_cus(p0.B)):
-            if second is not None:
-                second.wait_stream(cur_s)
+        lanes = eng.scoring_lanes(3)
+        with eng.scoring_session(sweep_cus=None if len(lanes) == 1 else eng.two_lane_sweep_cus(p0.B)):
+            if len(lanes) > 1:
+                for s_ in lanes[1:]:
+                    s_.wait_stream(cur_s)
                 for timed in (False, True):
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     for k_, p_ in enumerate(some * (3 if timed else 1)):
-                        with torch.cuda.stream((cur_s, second)[k_ & 1]):
-                            eng.score(p_, topk=100, seed=3, slot=k_ & 1)
-                    cur_s.wait_stream(second)
+                        with torch.cuda.stream(lanes[k_ % len(lanes)]):
+                            eng.score(p_, topk=100, seed=3, slot=k_ % len(lanes))
+                    for s_ in lanes[1:]:
+                        cur_s.wait_stream(s_)
                     torch.cuda.synchronize()
                     lanes_ms = (time.perf_counter() - t0) * 1e3 / (3 * len(some))
         ev_leg = dict(users=p0.B, rows=p0.R, score_ms=score_ms, users_per_s=p0.B / (score_ms * 1e-3),
-                      two_lanes=(None if lanes_ms is None else dict(
+                      lanes=(None if lanes_ms is None else dict(
                           ms_per_batch=lanes_ms, users_per_s=sum(p_.B for p_ in some) / len(some) / (lanes_ms * 1e-3),
-                          note="scoring_session(): two batches in flight on two streams, 8 plans x 3")),
+                          note="scoring_session(): %d batches in flight on %d streams, 8 plans x 3" % (len(lanes), len(lanes)))),
                       topk=dict(kernel="svae_masked_topk (k=100)", ms=topk_ms, algorithmic_bytes=tb, bound="hbm",
                                 achieved=tb / (topk_ms * 1e-3) / 1e9, peak=PEAK["hbm"], unit="GB/s",
                                 frac=tb / (topk_ms * 1e-3) / 1e9 / PEAK["hbm"]))

@@ -126,7 +126,7 @@ class SVAEEngine:
         self._slot = 0
         self.score_cus = None          # workgroups of the loss-only sweep of `score` (None: the CU count); see scoring_session
         self._slot_main = None         # (ws, loss_out) of slot 0 while slot 1 is current
-        self._slot1 = None             # (ws, loss_out, cap) of slot 1
+        self._slots = {}               # slot (1, 2) -> (ws, loss_out, cap)
         # row splits of the weight-gradient GEMMs (end of round 2, tools/sweep_env.sh, ms per step on one box, two
         # rounds: 32 -> 0.868 / 0.870, 16 -> 0.867 / 0.870, 24 -> 0.868 / 0.869, 21 -> 0.881 / 0.879, 48 -> 0.883 / 0.881)
         self.nsplit = int(_opt("SVAE_NSPLIT", "32"))
@@ -339,20 +339,22 @@ class SVAEEngine:
         return ws
 
     def _use_slot(self, k):
-        """Make workspace `k` (0: the engine's own; 1: the forward-only second one of a scoring session) current."""
+        """Make workspace `k` (0: the engine's own; 1, 2: the forward-only ones of a scoring session) current."""
         if k == self._slot:
             return
-        if k == 1:
-            if self._slot1 is None or self._slot1[2] != self.cap:
-                if self._slot1 is not None:            # (grown: its kernels may still be running)
-                    torch.cuda.synchronize(self.device)
-                self._slot1 = (self._new_ws(self.cap, forward_only=True), torch.zeros_like(self.loss_out), self.cap)
-            self._slot_main = (self.ws, self.loss_out)
-            self.ws, self.loss_out = self._slot1[0], self._slot1[1]
-        else:
+        if self._slot != 0:                            # back to the engine's own first
             self.ws, self.loss_out = self._slot_main
             self._slot_main = None
-        self._slot = k
+            self._slot = 0
+        if k != 0:
+            have = self._slots.get(k)
+            if have is None or have[2] != self.cap:
+                if have is not None:                   # (grown: its kernels may still be running)
+                    torch.cuda.synchronize(self.device)
+                have = self._slots[k] = (self._new_ws(self.cap, forward_only=True), torch.zeros_like(self.loss_out), self.cap)
+            self._slot_main = (self.ws, self.loss_out)
+            self.ws, self.loss_out = have[0], have[1]
+            self._slot = k
 
     @contextlib.contextmanager
     def scoring_session(self, sweep_cus=None):
@@ -394,12 +396,22 @@ class SVAEEngine:
         on two lanes: 160: 0.333, 176: 0.330, 192: 0.322, 208: 0.329, 224: 0.331, 256: 0.334."""
         return max(self._ncu // 2, self._ncu - (int(batch_users) + 3) // 4)
 
-    def scoring_stream(self):
-        """A stream that runs concurrently with the current one (the engine's measured side stream), for slot 1 of a
-        scoring session; None where the engine has none (no overlap, non-fused modes)."""
+    def scoring_lanes(self, n=3):
+        """[the current stream, side streams ...]: the streams batches of a scoring session alternate between, slot k on
+        lane k (ML-20M shape, B = 256, ms per batch: one lane 0.454, two 0.310, three 0.282)."""
+        lanes = [torch.cuda.current_stream()]
+        for w in range(max(0, min(int(n), 3) - 1)):
+            s_ = self.scoring_stream(w)
+            if s_ is not None:
+                lanes.append(s_)
+        return lanes
+
+    def scoring_stream(self, which=0):
+        """A stream that runs concurrently with the current one (the engine's measured side streams: which = 0, 1), for
+        slots 1 and 2 of a scoring session; None where the engine has none (no overlap, non-fused modes)."""
         if not (self.fused and self.overlap):
             return None
-        return self._side_stream(cur=torch.cuda.current_stream())
+        return self._side_stream(which, cur=torch.cuda.current_stream())
 
     def _ps(self, which):
         """Part stride (elements) of the bf16 operand images: 'rows' (h2b / h2s / h2tb) or 'items' (w3b / w3s / w3tb);
@@ -1656,8 +1668,8 @@ class SVAEEngine:
         Returns (loss_out, idx [B, k] int32, val [B, k]) in the plan's SORTED user order.
         slot = 1 (inside ``scoring_session`` only): the call works in the engine's second workspace, so that it may be
         issued on another stream while a slot-0 call is still running; its loss_out is the slot's own."""
-        if slot not in (0, 1) or (slot == 1 and not self._session):
-            raise ValueError("score(slot=1) needs an open scoring_session()")
+        if slot not in (0, 1, 2) or (slot != 0 and not self._session):
+            raise ValueError("score(slot=1 | 2) needs an open scoring_session()")
         self._use_slot(0)
         self._ensure(plan.R)                      # (the workspace grows on slot 0; slot 1 follows its size)
         self._use_slot(slot)

@@ -595,7 +595,7 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
 
     Later calls on the same reader (fit() evaluates every epoch) find their plans resident on the device
     (``reader._svae_eval_plans``, up to EVAL_PLAN_CACHE_BYTES) and start no builder threads; the batches are scored
-    two at a time on two streams inside one ``engine.scoring_session()``.
+    three at a time on three streams inside one ``engine.scoring_session()``.
 
     world > 1 (data parallel, torch.distributed initialised): the user batches are dealt round-robin to the ranks,
     every rank scores its share, and the per-user metric rows (7 float64 per user) and per-batch loss sums are
@@ -652,18 +652,17 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
     hflat_d = torch.from_numpy(hflat).to(eng.device)
     hoff_d = torch.from_numpy(hoff).to(eng.device)
     rank_dev = torch.full((max(1, len(hflat)),), -2, device=eng.device, dtype=torch.int32)
-    # The parameters do not change in here: one scoring session (the parameter-derived operands made once) and two
-    # workspaces -- even batches on the caller's stream, odd ones on a second stream beside them, so that the
-    # recurrence of one batch (a quarter of the chip) runs beside the sweep of the other.
+    # The parameters do not change in here: one scoring session (the parameter-derived operands made once) and up to
+    # three workspaces -- the batches alternate between the caller's stream and the engine's two side streams, so that
+    # the recurrence of one batch (a quarter of the chip) runs beside the sweeps of the others.
     cur = torch.cuda.current_stream()
-    second = eng.scoring_stream()
+    lanes = eng.scoring_lanes(3)
     # (the sweep's width does not depend on how many batches THIS rank scores: a batch's loss has the same bits wherever
     #  it is scored -- the sharded evaluation equals the single-process one exactly)
-    with eng.scoring_session(sweep_cus=None if second is None else eng.two_lane_sweep_cus(batch_size)):
-        lanes = [cur] if second is None or len(my_starts) < 2 else [cur, second]
-        second = second if len(lanes) == 2 else None
-        if second is not None:
-            second.wait_stream(cur)               # (the arrays above were filled on the caller's stream)
+    with eng.scoring_session(sweep_cus=None if len(lanes) == 1 else eng.two_lane_sweep_cus(batch_size)):
+        lanes = lanes[:max(1, min(len(lanes), len(my_starts)))]
+        for s_ in lanes[1:]:
+            s_.wait_stream(cur)                   # (the arrays above were filled on the caller's stream)
         for ci, (s0, plan) in enumerate(zip(my_starts, plans)):
             n = plan.B
             slot = ci % len(lanes)
@@ -679,8 +678,8 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
                 _lib.call("svae_heldout_ranks", idx.data_ptr(), n, int(idx.shape[1]), plan.row_key.data_ptr(),
                           plan.last_row.data_ptr(), hflat_d.data_ptr(), hoff_d.data_ptr(), len(pairs), rank_dev.data_ptr(),
                           _stream())
-        if second is not None:
-            cur.wait_stream(second)
+        for s_ in lanes[1:]:
+            cur.wait_stream(s_)
     if keep is not None and len(keep) == len(my_starts) and eps_list is None:
         try:
             reader._svae_eval_plans = (pkey, cache, keep)

@@ -514,9 +514,9 @@ def test_scoring_does_not_depend_on_the_batch_before_it():
         assert torch.equal(a, b)
 
 
-def test_scoring_session_on_two_lanes_equals_call_by_call_scoring():
-    """engine.scoring_session(): parameter-derived operands made once, batches alternating between the engine's two
-    workspaces on two streams (what notebook_api.evaluate does).  Six batches of unequal size -- the largest LAST, so the
+def test_scoring_session_on_three_lanes_equals_call_by_call_scoring():
+    """engine.scoring_session(): parameter-derived operands made once, batches alternating between the engine's three
+    workspaces on three streams (what notebook_api.evaluate does).  Six batches of unequal size -- the largest LAST, so the
     workspaces grow inside the session -- against the same batches scored one call at a time outside a session: loss,
     top-100 ids and values bit-identical; the poisoned variant fills both workspaces with NaN between two passes (a
     slot must not read what the batch before left).  A training step after the session sees fresh operands again."""
@@ -547,21 +547,23 @@ def test_scoring_session_on_two_lanes_equals_call_by_call_scoring():
     for poisoned in (False, True):
         got = []
         with eng2.scoring_session():
-            second = eng2.scoring_stream()
-            assert second is not None
-            second.wait_stream(cur)
+            lanes = eng2.scoring_lanes(3)
+            assert len(lanes) == 3 and lanes[0] is not lanes[1] and lanes[1] is not lanes[2]
+            for s_ in lanes[1:]:
+                s_.wait_stream(cur)
             for k, p in enumerate(plans):
-                with torch.cuda.stream((cur, second)[k & 1]):
-                    loss, idx, val, _ = eng2.score(p, 100, seed=3, step=k, slot=k & 1)
+                with torch.cuda.stream(lanes[k % 3]):
+                    loss, idx, val, _ = eng2.score(p, 100, seed=3, step=k, slot=k % 3)
                     got.append((loss.clone(), idx.clone(), val.clone()))
-            cur.wait_stream(second)
+            for s_ in lanes[1:]:
+                cur.wait_stream(s_)
         torch.cuda.synchronize()
         for k, (a, b) in enumerate(zip(ref, got)):
             for x, y in zip(a, b):
                 assert torch.isfinite(y.float()).all(), (poisoned, k)
                 assert torch.equal(x, y), (poisoned, k)
         if not poisoned:
-            for ws in (eng2.ws, eng2._slot1[0]):
+            for ws in (eng2.ws, eng2._slots[1][0], eng2._slots[2][0]):
                 for v in ws.values():
                     if v is not None and v.numel() and v.dtype == torch.float32:
                         v.fill_(float("nan"))

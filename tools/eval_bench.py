@@ -34,21 +34,21 @@ dt = time.perf_counter() - t0
 
 # the same plans inside a scoring session: parameter-derived operands made once, batches alternating between two
 # workspaces on two streams (what notebook_api.evaluate does)
-def session_pass(reps, sweep_cus=None):
+def session_pass(reps, sweep_cus=None, nlanes=2):
     cur = torch.cuda.current_stream()
     with eng.scoring_session(sweep_cus=sweep_cus):
-        second = eng.scoring_stream()
-        lanes = [cur] if second is None else [cur, second]
-        if second is not None:
-            second.wait_stream(cur)
+        lanes = [cur] + [eng.scoring_stream(w) for w in range(nlanes - 1)]
+        lanes = [s_ for s_ in lanes if s_ is not None]
+        for s_ in lanes[1:]:
+            s_.wait_stream(cur)
         k = 0
         for _ in range(reps):
             for p in plans:
                 with torch.cuda.stream(lanes[k % len(lanes)]):
                     eng.score(p, 100, seed=1, slot=k % len(lanes))
                 k += 1
-        if second is not None:
-            cur.wait_stream(second)
+        for s_ in lanes[1:]:
+            cur.wait_stream(s_)
 
 
 session_pass(1)
@@ -65,6 +65,14 @@ for cus in (160, 176, 192, 208, 224, 240):
     session_pass(3, cus)
     torch.cuda.synchronize()
     by_cus[cus] = (time.perf_counter() - t0) / (3 * len(plans)) * 1e3
+three = {}
+for cus in (128, 160, 192, 256):
+    session_pass(1, cus, 3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    session_pass(3, cus, 3)
+    torch.cuda.synchronize()
+    three[cus] = (time.perf_counter() - t0) / (3 * len(plans)) * 1e3
 # the top-k kernel alone
 st = torch.cuda.current_stream().cuda_stream
 p = plans[0]
@@ -154,7 +162,7 @@ print(json.dumps({"metric": "users scored/s (ML-20M shape, top-100)", "value": n
                   "evaluate_end_to_end": end_to_end,
                   "ms_per_batch": dt / (3 * len(plans)) * 1e3,
                   "scoring_session_two_lanes": {"users_per_s": n / dt_session, "ms_per_batch": dt_session / (3 * len(plans)) * 1e3,
-                                                "ms_per_batch_by_sweep_workgroups": by_cus},
+                                                "ms_per_batch_by_sweep_workgroups": by_cus, "three_lanes_ms_per_batch_by_sweep_workgroups": three},
                   "masked_topk": {"us": us, "algorithmic_bytes": algo, "GB/s": algo / us / 1e3,
                                   "frac_of_8TB/s": algo / us / 1e3 / 8000.0},
                   "masked_topk_2048_users": {"us": us_big, "GB/s": 8 * algo / us_big / 1e3,
