@@ -93,7 +93,8 @@ int svae_embed_bwd(const float* demb, const int* perm, const int* seg_off, const
 int svae_gru_fwd(const float* gi, const float* whh, const float* bhh, const int* row_off, const int* nact, int B,
                  int Tmax, float* hs, float* hprev, float* gates4, int prec, void* stream);
 /* Timesteps [t0, t1) of the same recurrence; t0 > 0 continues from hs (bf16 kernel only).  No counterpart in the
- * reference (one nn.GRU call, nb:759): the host runs the second range beside the decoder side of the first. */
+ * reference (one nn.GRU call, nb:759): the host runs the second range beside the decoder side of the first.
+ * prec 1 / 2: hprev and gates4 may BOTH be NULL when no backward follows (scoring): the saved state is not written. */
 int svae_gru_fwd_range(const float* gi, const float* whh, const float* bhh, const int* row_off, const int* nact, int B,
                        int Tmax, int t0, int t1, float* hs, float* hprev, float* gates4, int prec, void* stream);
 /* svae_gru_bwd with dgh == NULL (bf16 kernel): dgi is ONE array [R][896] = (dr, dz, dn, dn*r) that carries both

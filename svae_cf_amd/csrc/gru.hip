@@ -436,8 +436,10 @@ __device__ __forceinline__ void gru_fwd_bf16_body(const GruArgs& a, unsigned sho
     const unsigned R = (unsigned)roff_s[a.Tmax];
     const __amdgpu_buffer_rsrc_t gi_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, R * (SV_G * 4u), SV_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t hs_b = __builtin_amdgcn_make_buffer_rsrc(a.hs, 0, R * (SV_HP * 4u), SV_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t hp_b = __builtin_amdgcn_make_buffer_rsrc(a.hprev, 0, R * (SV_HP * 4u), SV_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t g4_b = __builtin_amdgcn_make_buffer_rsrc(a.gates4, 0, R * (SV_HP * 16u), SV_BUF_FLAGS);
+    // (hprev / gates4 NULL = a forward that no backward follows (scoring): zero-sized buffers, every store of the saved
+    //  state is out of range and dropped -- 5.4 KB per row that nobody reads; the loop itself is unchanged)
+    const __amdgpu_buffer_rsrc_t hp_b = __builtin_amdgcn_make_buffer_rsrc(a.hprev, 0, a.hprev ? R * (SV_HP * 4u) : 0u, SV_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t g4_b = __builtin_amdgcn_make_buffer_rsrc(a.gates4, 0, a.gates4 ? R * (SV_HP * 16u) : 0u, SV_BUF_FLAGS);
     int na = nact_s[a.t0];
     int rbase = roff_s[a.t0] + u0;
     if (a.t0 > 0) {
@@ -893,8 +895,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 1) void gru_bwd_bf16_kernel(GruArgs
 
 }  // namespace
 
-static int check_gru(const GruArgs& a, bool bwd) {
-    SV_CHECK_ARG(a.whh && a.row_off && a.nact && a.hprev && a.gates4, "svae_gru: null pointer");
+static int check_gru(const GruArgs& a, bool bwd, bool saved_optional = false) {
+    SV_CHECK_ARG(a.whh && a.row_off && a.nact, "svae_gru: null pointer");
+    SV_CHECK_ARG(saved_optional ? ((a.hprev == nullptr) == (a.gates4 == nullptr)) : (a.hprev && a.gates4),
+                 "svae_gru: hprev / gates4 (only the bf16 and split forward kernels may leave BOTH out)");
     SV_CHECK_ARG(a.B > 0 && a.Tmax > 0, "svae_gru: empty batch (B=%d Tmax=%d)", a.B, a.Tmax);
     if (!bwd) SV_CHECK_ARG(a.gi && a.bhh && a.hs, "svae_gru_fwd: null pointer");
     if (bwd) SV_CHECK_ARG(a.dhs && a.dgi && a.dgh, "svae_gru_bwd: null pointer");
@@ -918,7 +922,7 @@ extern "C" int svae_gru_fwd_range(const float* gi, const float* whh, const float
                                   const int* nact, int B, int Tmax, int t0, int t1, float* hs, float* hprev,
                                   float* gates4, int prec, void* stream) {
     GruArgs a{gi, whh, bhh, row_off, nact, hs, hprev, gates4, nullptr, nullptr, nullptr, B, Tmax, 0, t0, t1};
-    if (int e = check_gru(a, false)) return e;
+    if (int e = check_gru(a, false, prec != 0)) return e;
     SV_CHECK_ARG(prec == 0 || prec == 1 || prec == 2, "svae_gru_fwd: bad prec %d", prec);
     SV_CHECK_ARG(t0 >= 0 && t0 < t1 && t1 <= Tmax, "svae_gru_fwd_range: bad range [%d, %d) of %d", t0, t1, Tmax);
     SV_CHECK_ARG(prec != 0 || (t0 == 0 && t1 == Tmax), "svae_gru_fwd_range: the fp32 kernel runs whole sequences only");

@@ -306,7 +306,7 @@ class SVAEEngine:
 
     # what only backward writes or reads: a forward-only workspace (slot 1 of a scoring session) leaves them empty
     _BACKWARD_ONLY = ("dgh", "dg4", "dz", "dtmp", "dd1", "denc", "dhs", "dgi", "demb", "dg4b", "hprev16", "mpart",
-                      "pslabs", "pslabs_side")
+                      "pslabs", "pslabs_side", "hprev", "gates4")
 
     def _new_ws(self, cap, forward_only=False):
         f32 = dict(device=self.device, dtype=torch.float32)
@@ -741,12 +741,16 @@ class SVAEEngine:
         t1, r1 = (plan.split_t, plan.split_r) if (self.time_split and side_prep and want_loss
                                                   and want_grad and self.gru_prec in (PREC_BF16, PREC_SPLIT)) else (0, 0)
 
+        # h_{t-1} and the gates are saved for the BPTT only: a forward without gradients (scoring) leaves them out
+        # (bf16 / split recurrence kernels; 5.4 KB per row of HBM writes)
+        save_state = bool(want_grad or self.gru_prec == PREC_FP32)
+
         def gru_range(a, b, tag):
             ev = self._tic(tag)
             _lib.call("svae_gru_fwd_range", w["gi"].data_ptr(), self.P("gru.weight_hh_l0").data_ptr(),
                       self.P("gru.bias_hh_l0").data_ptr(), plan.row_off.data_ptr(), plan.nact.data_ptr(),
-                      plan.B, plan.Tmax, a, b, w["hs"].data_ptr(), w["hprev"].data_ptr(), w["gates4"].data_ptr(),
-                      self.gru_prec, _stream())
+                      plan.B, plan.Tmax, a, b, w["hs"].data_ptr(), w["hprev"].data_ptr() if save_state else None,
+                      w["gates4"].data_ptr() if save_state else None, self.gru_prec, _stream())
             self._toc(tag, ev)
 
         # Host order = critical path first: the recurrence that heads the step is enqueued before the side stream's
