@@ -138,7 +138,8 @@ int svae_mlp_fwd(const float* hs, const float* eps, const void* frags, const flo
 
 /* svae_mlp_fwd over rows [row0, row1) of the batch (same reference lines) that also writes the projection sweeps'
  * bf16 operand copies of d1 -- what svae_proj_prep_rows_range makes from d1, bit for bit -- so the decoder side
- * runs one kernel less.  Pointers are array bases; row0 % 32 == 0; row1 <= R_pad (R_pad % 64 == 0). */
+ * runs one kernel less.  Pointers are array bases; row0 % 32 == 0; row1 <= R_pad (R_pad % 64 == 0).
+ * enc, tmp and z may all be NULL when no backward follows (scoring): they are then not written. */
 int svae_mlp_fwd_prep(const float* hs, const float* eps, const void* frags, const float* b1, const float* bl,
                       const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R, int R_pad,
                       int row0, int row1, void* h2b, void* h2s, void* h2tb, void* stream);

@@ -258,6 +258,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
     const int r = (PREP ? a.row0 : 0) + (blockIdx.x * 4 + wave) * 32 + li;
     const bool ok = r < a.R && (!PREP || r < a.row1);
     const size_t rc = ok ? r : a.R - 1;          // loads are clamped, stores masked
+    // enc / tmp / z are what the backward reads; a forward without one (scoring) passes them NULL and keeps d1 only
+    const bool ok_act = ok && a.enc != nullptr;
 
 #ifdef SV_MLP_TIMING
     unsigned long long ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
             mm<SPLIT>(c, wlds, OFF_F1 + nt * KS_H + s, a.frags, OFF_F1 + nt * KS_H + s, lane, hb[s]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) c[i] = mlp_tanh<SPLIT>(c[i]);
-        tile_store(a.enc + rc * SV_DP, nt, lh, c, ok);
+        tile_store(a.enc + rc * SV_DP, nt, lh, c, ok_act);
         to_frags<SPLIT>(c, pe[2 * nt], pe[2 * nt + 1]);
     }
     SV_MTS(4)
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int s = 0; s < KS_D; ++s)
             mm<SPLIT>(t[nt], wlds, OFF_F2 + nt * KS_D + s, a.frags, OFF_F2 + nt * KS_D + s, lane, pe[s]);
-        tile_store(a.tmp + rc * SV_L2, nt, lh, t[nt], ok);
+        tile_store(a.tmp + rc * SV_L2, nt, lh, t[nt], ok_act);
     }
     // ---- z = mu + exp(ls) eps, KL row term (log_sigma is a log-std for sampling and a log-variance in KL:
     //      reproduced as the reference has it, nb:743 / nb:797)
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdArgs a) {
                 kl += 0.5f * (-ls + sg + mu * mu - 1.0f);
             }
         }
-        tile_store(a.z + rc * SV_L, q, lh, zt, ok);
+        tile_store(a.z + rc * SV_L, q, lh, zt, ok_act);
         to_frags<SPLIT>(zt, pz[2 * q], pz[2 * q + 1]);
     }
     kl += __shfl_xor(kl, 32, 64);
@@ -559,8 +561,9 @@ extern "C" int svae_mlp_fwd_prep(const float* hs, const float* eps, const void* 
                                  const float* b2, float* enc, float* tmp, float* z, float* d1, float* kl_row, int R,
                                  int R_pad, int row0, int row1, void* h2b, void* h2s, void* h2tb, void* stream) {
     // (h2tb may be NULL: the bf16 sweeps read the transpose out of the row-major image)
-    SV_CHECK_ARG(hs && eps && frags && b1 && bl && b2 && enc && tmp && z && d1 && kl_row && h2b && h2s,
-                 "svae_mlp_fwd_prep: null pointer");
+    SV_CHECK_ARG(hs && eps && frags && b1 && bl && b2 && d1 && kl_row && h2b && h2s, "svae_mlp_fwd_prep: null pointer");
+    // (enc, tmp, z: all three or none -- none when no backward follows: they are then not written)
+    SV_CHECK_ARG((enc && tmp && z) || (!enc && !tmp && !z), "svae_mlp_fwd_prep: enc / tmp / z must be given together");
     SV_CHECK_ARG(R > 0 && R_pad >= R && (R_pad % 64) == 0 && row0 >= 0 && row0 < row1 && row1 <= R_pad && (row0 % 32) == 0 &&
                  row0 < R, "svae_mlp_fwd_prep: bad range [%d, %d) of %d (%d)", row0, row1, R, R_pad);
     MlpFwdArgs a{hs, eps, (const unsigned short*)frags, b1, bl, b2, enc, tmp, z, d1, kl_row, R, (unsigned short*)h2b,

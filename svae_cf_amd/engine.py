@@ -851,7 +851,8 @@ class SVAEEngine:
             # copies of its last output in the same kernel -- scoring's forward takes this path at every call
             rows_prepared = bool(want_loss and self.fused_prep)
             if rows_prepared:
-                self._decoder_rows(plan, 0, R, self._ncu, sweep=False)
+                # (enc / mu, log sigma / z are the backward's inputs: a forward without gradients does not write them)
+                self._decoder_rows(plan, 0, R, self._ncu, sweep=False, save_acts=bool(want_grad))
             else:
                 self._mlp_fwd_rows(0, R)
         else:
@@ -919,7 +920,7 @@ class SVAEEngine:
                   w["d1"].data_ptr() + 4 * DP * r0, w["kl_row"].data_ptr() + 4 * r0, n, self.prec, _stream())
         self._toc("mlp_fwd", ev)
 
-    def _decoder_rows(self, plan, r0, r1, ncu, mlp=True, sweep=True):
+    def _decoder_rows(self, plan, r0, r1, ncu, mlp=True, sweep=True, save_acts=True):
         """Decoder side of rows [r0, r1) of the plan (r0 a multiple of 64): MLP chain, bf16 operand copies (mlp),
         forward + dL/dh sweep of the projection and its finish (sweep).  Every array is row-major, so a row range is
         a pointer offset; the slab scratch of a range starts where the previous range's ends."""
@@ -932,8 +933,9 @@ class SVAEEngine:
             ev = self._tic("mlp_fwd")
             _lib.call("svae_mlp_fwd_prep", w["hs"].data_ptr(), w["eps"].data_ptr(), self.mlp_frags.data_ptr(),
                       self.P("encoder.linear1.bias").data_ptr(), self.P("linear1.bias").data_ptr(),
-                      self.P("decoder.linear1.bias").data_ptr(), w["enc"].data_ptr(), w["tmp"].data_ptr(),
-                      w["z"].data_ptr(), w["d1"].data_ptr(), w["kl_row"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
+                      self.P("decoder.linear1.bias").data_ptr(), w["enc"].data_ptr() if save_acts else None,
+                      w["tmp"].data_ptr() if save_acts else None, w["z"].data_ptr() if save_acts else None,
+                      w["d1"].data_ptr(), w["kl_row"].data_ptr(), R, Rp, r0, Rp if r1 == R else r1,
                       w["h2b"].data_ptr(), w["h2s"].data_ptr(), _lib.ptr(w["h2tb"]), _stream())
             self._toc("mlp_fwd", ev)
         else:
