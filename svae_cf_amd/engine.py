@@ -333,8 +333,10 @@ class SVAEEngine:
             ws["pslabs"] = torch.empty(nsm * capp * DP, **f32)
             ws["pslabs_side"] = torch.empty(nsm * self.IPAD * DP, **f32)
         if forward_only:
+            # (the generic fp32 recurrence always writes its saved state: SVAE_SPLIT_GRU_F32, a tuning switch)
+            keep = ("hprev", "gates4") if self.gru_prec == PREC_FP32 else ()
             for k in self._BACKWARD_ONLY:
-                if k in ws:
+                if k in ws and k not in keep:
                     ws[k] = torch.empty(0, device=self.device, dtype=ws[k].dtype)
         return ws
 
