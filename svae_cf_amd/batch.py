@@ -382,6 +382,9 @@ def _copy_stream(device):
     return st
 
 
+CONSUMER_UPLOADS = True      # PlanPrefetcher's default (tools flip it for A/B runs)
+
+
 class PlanPrefetcher:
     """Builds the plans of an epoch AHEAD of the GPU: worker threads run the library's plan builder over a UserCSR
     (one C call of about 0.45 ms for a 256-user ML-20M-shaped batch, made without the interpreter lock; a plain list
@@ -399,16 +402,59 @@ class PlanPrefetcher:
     workers against 0.95 ms with every plan resident beforehand (0.92x); three and more workers were SLOWER (1.20-1.24
     ms: the loop is then never blocked on plans, the step itself stretches), hence the default of two."""
 
-    def __init__(self, batches, users, next_k, device, total_items=None, prepare=None, workers=2, depth=8):
+    def __init__(self, batches, users, next_k, device, total_items=None, prepare=None, workers=2, depth=8,
+                 consumer_uploads=None, ahead=2):
+        """prepare: callable(plan), or a pair (host_half(plan) -> made, upload_half(plan, made)) as
+        ``(engine.prepare_host, engine.prepare_upload)``.
+        consumer_uploads (UserCSR input on a GPU): the builder threads make NO device call -- they pack the plan into
+        a pinned buffer (and run the host half of `prepare`); the CONSUMER's thread issues the copy on the copy stream,
+        `ahead` plans ahead of the one it hands out.  With uploads issued from the builder threads the consumer's
+        kernel launches and the builders' copies met inside the HIP runtime: a scoring call's host time rose from
+        0.11 to 0.25-0.35 ms beside two or three builders (tools/probe/evaluate_workers.py)."""
         from concurrent.futures import ThreadPoolExecutor
         self.batches, self.users, self.k = list(batches), users, next_k
         self.pool_pinned = _PinnedPool()
         self.wait_s = 0.0
-        self.device, self.total_items, self.prepare = torch.device(device), total_items, prepare
+        self.device, self.total_items = torch.device(device), total_items
+        if isinstance(prepare, tuple):
+            self.prepare_host, self.prepare_upload = prepare
+            self.prepare = lambda p_: self.prepare_upload(p_, self.prepare_host(p_))
+        else:
+            self.prepare, self.prepare_host, self.prepare_upload = prepare, None, None
         self.depth = max(1, int(depth))
+        self.ahead = max(1, int(ahead))
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
         # ONE copy stream per device and process (a prefetcher is made per epoch; streams are a finite resource)
         self.copy_stream = _copy_stream(self.device) if self.device.type == "cuda" else None
+        if consumer_uploads is None:
+            consumer_uploads = CONSUMER_UPLOADS
+        self.consumer_uploads = bool(consumer_uploads and self.copy_stream is not None and isinstance(users, UserCSR))
+
+    def _build_host(self, idx):
+        """Builder thread, consumer_uploads: the plan in a pinned host buffer, the engine's tables on the host."""
+        taken = []
+
+        def alloc(n):
+            taken.append(self.pool_pinned.take(n))
+            return taken[-1]
+        plan = build_plan_native(self.users, idx, self.k, user_keys=idx, total_items=self.total_items, host_alloc=alloc)
+        made = self.prepare_host(plan) if self.prepare_host is not None else None
+        return plan, made, taken[0]
+
+    def _upload(self, plan, made, host):
+        """Consumer's thread: the copy (and the tables') on the copy stream, the event the consumer's stream waits for."""
+        with torch.cuda.stream(self.copy_stream):
+            plan.to(self.device, stream=self.copy_stream)
+            plan._host = None
+            if self.prepare_upload is not None:
+                self.prepare_upload(plan, made)
+            elif self.prepare is not None:
+                self.prepare(plan)
+            if self.prepare is not None:
+                plan.ready = torch.cuda.Event()
+                plan.ready.record(self.copy_stream)
+        self.pool_pinned.give(host, plan.ready)
+        return plan
 
     def _make(self, idx):
         users = self.users
@@ -438,18 +484,34 @@ class PlanPrefetcher:
     def __iter__(self):
         from collections import deque
         q, it = deque(), iter(self.batches)
+        make = self._build_host if self.consumer_uploads else self._make
+        up = deque()                                   # consumer_uploads: plans whose copy has been issued
         try:
             for idx in it:
-                q.append(self.pool.submit(self._make, idx))
+                q.append(self.pool.submit(make, idx))
                 if len(q) >= self.depth:
                     break
-            while q:
+            while q or up:
+                if self.consumer_uploads:
+                    # issue the copies of the plans that are built, up to `ahead` beyond the one handed out; wait only
+                    # when there is nothing to hand out
+                    while q and len(up) <= self.ahead and (not up or q[0].done()):
+                        t0 = time.perf_counter()
+                        built = q.popleft().result()
+                        if not up:
+                            self.wait_s += time.perf_counter() - t0
+                        up.append(self._upload(*built))
+                        nxt = next(it, None)
+                        if nxt is not None:
+                            q.append(self.pool.submit(make, nxt))
+                    yield up.popleft()
+                    continue
                 t0 = time.perf_counter()
                 plan = q.popleft().result()
                 self.wait_s += time.perf_counter() - t0          # the consumer's time blocked on the builders
                 nxt = next(it, None)
                 if nxt is not None:
-                    q.append(self.pool.submit(self._make, nxt))
+                    q.append(self.pool.submit(make, nxt))
                 yield plan
         finally:
             for f in q:

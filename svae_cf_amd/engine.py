@@ -1072,14 +1072,24 @@ class SVAEEngine:
         the caller's stream in the middle of backward: the host waits for the GRU's BPTT and the weight-gradient
         sweep starts after it rather than beside it (seen in a kernel trace: +0.2-0.4 ms on a plan's first step).
         scoring: the plan will only be scored (``score``: the loss-only sweep over all rows)."""
+        return self.prepare_upload(plan, self.prepare_host(plan, scoring))
+
+    def prepare_host(self, plan, scoring=False):
+        """First half of ``prepare``: the tables this engine does not have yet, built on the host (no device call; a
+        prefetcher's builder threads run it).  Returns what ``prepare_upload`` takes."""
         if not self.fused:
-            return plan
+            return []
         want = [("rows", None, self.score_cus, False)] if scoring else [("rows", None, None, None), ("items", None, None, None)]
         if not scoring and self.time_split and plan.split_t > 0:
             want += [("rows", plan.split_r, self._range1_cus(plan), None),
                      ("rows", plan.R - plan.split_r, self._ncu, None)]
-        made = [m for m in (self._proj_sched(plan, sd, nx=nx, ncu=ncu, host_only=True, flat=fl) for sd, nx, ncu, fl in want)
+        return [m for m in (self._proj_sched(plan, sd, nx=nx, ncu=ncu, host_only=True, flat=fl) for sd, nx, ncu, fl in want)
                 if m is not None]
+
+    def prepare_upload(self, plan, made):
+        """Second half of ``prepare``: one asynchronous copy of the new tables on the current stream."""
+        # (a table another plan has uploaded since is found by shape when the sweep asks for it)
+        made = [m for m in made if m[0] not in plan.proj_sched and m[3] not in self._sched_cache]
         if not made:
             return plan
         # all tables through ONE pinned buffer and one asynchronous copy on the caller's current stream: a pageable

@@ -465,7 +465,7 @@ def train_batched(reader, model, hyper_params, batch_size=256, epoch=1, seed=0, 
     batches = rank_batches(lens_all, batch_size, rng, rank, world)
     if len(batches):
         eng.reserve(max(int(lens_all[np.asarray(b)].sum()) - len(b) for b in batches))   # rows = sum of (length - 1)
-    plans = PlanPrefetcher(batches, csr[1], k, eng.device, total_items=eng.I, prepare=eng.prepare,
+    plans = PlanPrefetcher(batches, csr[1], k, eng.device, total_items=eng.I, prepare=(eng.prepare_host, eng.prepare_upload),
                            workers=workers, depth=4 * workers)
     # the loop runs on the engine's high-priority stream (SVAEEngine.training_stream): the caller's chain of a step is
     # its critical path and shares the GPU with the engine's own side streams
@@ -641,7 +641,7 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
         plans = _ResidentPlans(held[2])
     else:
         plans = PlanPrefetcher(batches, csr, k, eng.device, total_items=eng.I,
-                               prepare=lambda p_: eng.prepare(p_, scoring=True), workers=workers, depth=2 * max(1, workers))
+                               prepare=(lambda p_: eng.prepare_host(p_, scoring=True), eng.prepare_upload), workers=workers, depth=2 * max(1, workers))
         held = None
     keep, keep_bytes = ([], 0) if held is None else (None, 0)
     kmax = max(Ks)

@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import svae_cf_amd as S
 from svae_cf_amd import synth, notebook_api as N
 from svae_cf_amd.batch import build_plan
+import svae_cf_amd.batch as _batch
+if os.environ.get('SVAE_CONSUMER_UPLOADS'):
+    _batch.CONSUMER_UPLOADS = os.environ['SVAE_CONSUMER_UPLOADS'] == '1'
 
 workers = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 if os.environ.get("SVAE_SWITCH_INTERVAL"):

@@ -8,6 +8,10 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import svae_cf_amd as S
 from svae_cf_amd import synth, notebook_api as N
+import svae_cf_amd.batch as _batch
+if os.environ.get('SVAE_CONSUMER_UPLOADS'):
+    _batch.CONSUMER_UPLOADS = os.environ['SVAE_CONSUMER_UPLOADS'] == '1'
+N.EVAL_PLAN_CACHE_BYTES = 0          # every call builds its plans (the first call on a reader)
 I, B = 20000, 256
 _, _, mu, sigma, lmax = synth.SHAPES["ml-20m"]
 eng = S.SVAEEngine(I, device="cuda", prec=S.PREC_BF16)
