@@ -388,8 +388,9 @@ CONSUMER_UPLOADS = True      # PlanPrefetcher's default (tools flip it for A/B r
 class PlanPrefetcher:
     """Builds the plans of an epoch AHEAD of the GPU: worker threads run the library's plan builder over a UserCSR
     (one C call of about 0.45 ms for a 256-user ML-20M-shaped batch, made without the interpreter lock; a plain list
-    of per-user arrays goes through the numpy ``build_plan``, 4 ms), pack each plan into a pooled pinned host buffer
-    and upload it on a copy stream of their own; the consumer gets the plans in order, each with an event
+    of per-user arrays goes through the numpy ``build_plan``, 4 ms) and pack each plan into a pooled pinned host buffer;
+    the copy goes out on the process's copy stream -- issued by the consumer's thread a few plans ahead
+    (``consumer_uploads``, below), or by the builders themselves -- and the consumer gets the plans in order, each with an event
     (``plan.ready``) that ``SVAEEngine.forward`` makes its stream wait for.  With the reference's data model -- a
     Python list of per-user item lists, nb:439-483 -- the per-user work of DataReader.iter (nb:485-526: x, the
     next-k targets) is what this replaces; it has to run somewhere, and here it runs beside the step before.
