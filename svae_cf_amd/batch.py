@@ -276,7 +276,7 @@ _NATIVE_ARRAYS = (("x", np.int32), ("tgt", np.int32), ("w_nll", np.float32), ("w
 
 
 def build_plan_native(csr, idx, next_k, user_keys=None, device=None, pin=False, total_items=None, stream=None,
-                      host_alloc=None, host_release=None):
+                      host_alloc=None, host_release=None, bind=True):
     """build_plan through the library's host-side builder (svae_plan_create / svae_plan_pack, csrc/plan.hip): same
     plan, byte for byte (tests/test_host_logic.py), for the users ``idx`` of a UserCSR -- one C call that holds no
     interpreter lock.  host_alloc(nbytes) -> uint8 host tensor to pack into (a pinned-buffer pool); host_release(
@@ -325,7 +325,8 @@ def build_plan_native(csr, idx, next_k, user_keys=None, device=None, pin=False, 
                if info.off[i] >= 0}
     p._host = host[:n]
     if device is None:
-        p._bind(p._host)
+        if bind:                  # (bind=False: the caller uploads it next and only then needs the tensor views)
+            p._bind(p._host)
         return p
     p.to(device, stream=stream)
     p._host = None
@@ -438,7 +439,8 @@ class PlanPrefetcher:
         def alloc(n):
             taken.append(self.pool_pinned.take(n))
             return taken[-1]
-        plan = build_plan_native(self.users, idx, self.k, user_keys=idx, total_items=self.total_items, host_alloc=alloc)
+        plan = build_plan_native(self.users, idx, self.k, user_keys=idx, total_items=self.total_items, host_alloc=alloc,
+                                 bind=False)
         made = self.prepare_host(plan) if self.prepare_host is not None else None
         return plan, made, taken[0]
 
