@@ -203,6 +203,48 @@ def test_evaluate_keeps_its_plans_on_the_device_between_calls():
     assert d[0]["loss"] != c[0]["loss"]
 
 
+@pytest.mark.parametrize("consumer_uploads", [True, False])
+def test_prefetched_plans_equal_directly_built_ones(consumer_uploads):
+    """PlanPrefetcher (builder threads; the uploads issued by the consumer's thread or by the builders) hands out, in
+    order, plans byte-identical to build_plan_native on the same users, with the engine's tables attached and an event to
+    wait for; leaving the loop early neither hangs nor leaks a worker."""
+    import svae_cf_amd as S
+    from svae_cf_amd import synth
+    from svae_cf_amd.batch import PlanPrefetcher, UserCSR, build_plan_native
+    Ibig = 5000
+    _, _, mu, sigma, lmax = synth.SHAPES["ml-1m"]
+    users = synth.make_users(400, Ibig, mu, sigma, lmax, seed=12)
+    csr = UserCSR([u.tolist() for u in users])
+    rng = np.random.default_rng(3)
+    batches = [np.sort(rng.choice(400, size=n, replace=False)).astype(np.int64) for n in (64, 7, 128, 33, 64, 90)]
+    eng = S.SVAEEngine(Ibig, device="cuda", prec=S.PREC_BF16)
+    pf = PlanPrefetcher(batches, csr, 4, eng.device, total_items=Ibig, prepare=(eng.prepare_host, eng.prepare_upload),
+                        workers=2, depth=4, consumer_uploads=consumer_uploads)
+    assert pf.consumer_uploads == consumer_uploads
+    cur = torch.cuda.current_stream()
+    n = 0
+    for idx, plan in zip(batches, pf):
+        assert plan.ready is not None and plan.x.is_cuda
+        cur.wait_event(plan.ready)
+        ref = build_plan_native(csr, idx, 4, user_keys=idx, device="cuda", total_items=Ibig)
+        assert (plan.B, plan.R, plan.Tmax, plan.K, plan.split_t, plan.split_r) == (ref.B, ref.R, ref.Tmax, ref.K, ref.split_t, ref.split_r)
+        assert set(plan._offs) == set(ref._offs)
+        for name in plan._offs:                                   # (the gaps between the packed arrays are not written)
+            assert torch.equal(getattr(plan, name), getattr(ref, name)), name
+        assert np.array_equal(plan.order, ref.order) and np.array_equal(plan._row_off_host, ref._row_off_host)
+        assert any(k[0] == "rows" for k in plan.proj_sched) or eng._sched_cache
+        out = eng.train_step(plan, 0.05, seed=1, step=n)          # (the plan is usable as handed out)
+        n += 1
+    torch.cuda.synchronize()
+    assert n == len(batches) and bool(torch.isfinite(out[0]))
+    pf2 = PlanPrefetcher(batches, csr, 4, eng.device, total_items=Ibig, prepare=eng.prepare, workers=2, depth=4,
+                         consumer_uploads=consumer_uploads)
+    for k, plan in enumerate(pf2):
+        if k == 1:
+            break                                                  # the generator's clean-up shuts the pool down
+    torch.cuda.synchronize()
+
+
 # ---------------------------------------------------------------------------------------------
 # the C-ABI's own collectives (svae_rccl_* / svae_allreduce_sum_f32 / reduce-scatter / all-gather): RCCL at world size 1
 # ---------------------------------------------------------------------------------------------
