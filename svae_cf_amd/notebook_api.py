@@ -649,8 +649,11 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
     loss_dev = torch.zeros(max(1, len(my_starts)), device=eng.device, dtype=torch.float32)
     # the hit search of nb:636-645 runs on the device (svae_heldout_ranks): every held-out item's position in its
     # user's top-100, written into ONE array for the whole evaluation and read back once at the end
-    hflat_d = torch.from_numpy(hflat).to(eng.device)
-    hoff_d = torch.from_numpy(hoff).to(eng.device)
+    if held is not None and len(held) > 3:           # (the held-out lists stay on the device with the plans)
+        hflat_d, hoff_d = held[3], held[4]
+    else:
+        hflat_d = torch.from_numpy(hflat).to(eng.device)
+        hoff_d = torch.from_numpy(hoff).to(eng.device)
     rank_dev = torch.full((max(1, len(hflat)),), -2, device=eng.device, dtype=torch.int32)
     # The parameters do not change in here: one scoring session (the parameter-derived operands made once) and up to
     # three workspaces -- the batches alternate between the caller's stream and the engine's two side streams, so that
@@ -682,7 +685,7 @@ def evaluate(model, criterion, reader, hyper_params, is_train_set, batch_size=25
             cur.wait_stream(s_)
     if keep is not None and len(keep) == len(my_starts) and eps_list is None:
         try:
-            reader._svae_eval_plans = (pkey, cache, keep)
+            reader._svae_eval_plans = (pkey, cache, keep, hflat_d, hoff_d)
         except AttributeError:
             pass
     t_loop = time.perf_counter()
